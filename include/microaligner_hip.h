@@ -1,0 +1,172 @@
+/*
+ * microaligner_hip.h -- C-ABI of the MI355X (gfx950) implementation of
+ * microaligner's optical-flow registration hot path.
+ *
+ * The reference (VasylVaskivskyi/microaligner v1.0.0) is pure Python and has no
+ * FFI layer of its own: on this path it calls six OpenCV functions and one
+ * scikit-learn function from the optflow_reg package and
+ * microaligner/shared_modules/similarity_scoring.py.  Each entry point below
+ * replaces one of those call sites (cited per function) with a batched HIP
+ * kernel pipeline; microaligner_amd/ binds them with ctypes and keeps the
+ * reference's Python class API on top (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - Every function returns MA_OK (0) or a negative ma_status; the message of
+ *    the last failure on the calling thread is ma_last_error().  No C++
+ *    exception crosses this boundary.
+ *  - Image/flow pointers are DEVICE pointers obtained from ma_malloc (or any
+ *    hipMalloc'ed memory of the ctx's device) unless a parameter is named
+ *    *_host.  Images are dense row-major (row stride = width * element size);
+ *    flows and maps are (h, w, 2) float32 interleaved (x, y) as OpenCV returns
+ *    them.
+ *  - Work is enqueued on the ctx's HIP stream; functions that return data to
+ *    the host synchronise that stream, the others do not (call ma_sync).
+ *  - One ma_ctx per device per process; a ctx is not thread-safe.
+ *  - dtype: MA_U8 / MA_U16 / MA_F32.
+ */
+#ifndef MICROALIGNER_HIP_H
+#define MICROALIGNER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ma_ctx ma_ctx;
+
+enum ma_dtype { MA_U8 = 0, MA_U16 = 1, MA_F32 = 2 };
+
+enum ma_status {
+    MA_OK = 0,
+    MA_EINVAL = -1, /* bad argument (Python raises ValueError) */
+    MA_ENOMEM = -2, /* host or device allocation failed */
+    MA_EHIP = -3,   /* a HIP runtime call failed (Python raises RuntimeError) */
+    MA_ENODEV = -4  /* no usable HIP device */
+};
+
+/* flags for ma_farneback_tiled */
+enum ma_farneback_flags {
+    MA_FB_MULADD_FUSED = 1 /* window blur uses fused multiply-add (models OpenCV builds whose
+                              v_muladd is an FMA); default is multiply-then-add (x86 SSE baseline) */
+};
+
+/* ---- library / context ------------------------------------------------- */
+const char* ma_version(void);
+const char* ma_last_error(void);
+int ma_device_count(int* count);
+int ma_ctx_create(int device, ma_ctx** out);
+void ma_ctx_destroy(ma_ctx* ctx);
+int ma_sync(ma_ctx* ctx);
+/* Upper bound, in bytes, for the internal tile-batch workspace (default 24 GiB). */
+int ma_ctx_set_workspace_limit(ma_ctx* ctx, size_t bytes);
+/* The ctx's hipStream_t as an opaque pointer (for event timing by the caller). */
+void* ma_ctx_stream(ma_ctx* ctx);
+
+/* ---- device memory (caller owns host buffers; library owns nothing it returns
+ *      except the error string) ------------------------------------------- */
+int ma_malloc(ma_ctx* ctx, size_t bytes, void** dptr);
+int ma_free(ma_ctx* ctx, void* dptr);
+int ma_memcpy_h2d(ma_ctx* ctx, void* dst, const void* src_host, size_t bytes);
+int ma_memcpy_d2h(ma_ctx* ctx, void* dst_host, const void* src, size_t bytes); /* synchronises */
+int ma_memcpy_d2d(ma_ctx* ctx, void* dst, const void* src, size_t bytes);
+int ma_memset(ma_ctx* ctx, void* dst, int value, size_t bytes);
+
+/* ---- timing (HIP events on the ctx stream) ------------------------------ */
+int ma_event_create(ma_ctx* ctx, void** ev);
+int ma_event_destroy(ma_ctx* ctx, void* ev);
+int ma_event_record(ma_ctx* ctx, void* ev);
+int ma_event_elapsed_ms(ma_ctx* ctx, void* ev_start, void* ev_stop, float* ms); /* synchronises on ev_stop */
+/* Per-kernel accounting: when enabled every kernel launch of the Farneback
+ * pipeline is bracketed by events; ma_profile_get returns accumulated time and
+ * launch count per kernel id (enum ma_kernel_id). */
+enum ma_kernel_id {
+    MA_K_POLYEXP_M0 = 0, MA_K_BLUR_V = 1, MA_K_BLUR_H_SOLVE = 2, MA_K_WARP = 3, MA_K_MERGE = 4,
+    MA_K_PYR_DOWN = 5, MA_K_PYR_UP = 6, MA_K_DOG = 7, MA_K_NMI = 8, MA_K_OTHER = 9, MA_K_COUNT = 10
+};
+int ma_profile_enable(ma_ctx* ctx, int on);
+int ma_profile_reset(ma_ctx* ctx);
+int ma_profile_get(ma_ctx* ctx, int kernel_id, double* total_ms, long long* launches, double* px);
+
+/* ---- Farneback ----------------------------------------------------------
+ * Replaces cv2.calcOpticalFlowFarneback(prev, next, None, pyr_scale=0.5,
+ * levels=0, winsize, iterations, poly_n, poly_sigma, OPTFLOW_FARNEBACK_GAUSSIAN)
+ * as called from microaligner/optflow_reg/flow_calc.py:33-44, together with
+ * TileFlowCalc's split -> fan-out -> stitch (flow_calc.py:59-98,
+ * shared_modules/slicer.py:69-118, stitcher.py:72-118).
+ *
+ * tile == 0: one Farneback call on the whole (H, W) image (flow_calc.py:60-64).
+ * tile  > 0: the image is cut into ceil(H/tile) x ceil(W/tile) windows of
+ *            (tile + 2*overlap)^2 pixels, zero padded outside the image; each
+ *            window is an independent Farneback problem with its own borders;
+ *            the centre [overlap, overlap+tile) of every window is written to
+ *            flow_out.  Bit-for-bit the tile-local semantics of the reference.
+ * prev = moving image, next = reference image (flow_calc.py:34-35).
+ * poly_n must be 1 (the only value the reference passes, flow_calc.py:41).
+ */
+int ma_farneback_tiled(ma_ctx* ctx, const void* prev, const void* next, int dtype, int H, int W,
+                       int tile, int overlap, int winsize, int iterations, int poly_n,
+                       double poly_sigma, int flags, float* flow_out);
+
+/* Debug/validation variant for one untiled plane pair: also returns the
+ * polynomial expansions (planar, 5 x H x W) and the first matrix field M. */
+int ma_farneback_debug(ma_ctx* ctx, const void* prev, const void* next, int dtype, int H, int W,
+                       int winsize, int iterations, double poly_sigma, int flags, float* flow_out,
+                       float* R0_planar, float* R1_planar, float* M0_planar);
+
+/* ---- remap / warp --------------------------------------------------------
+ * ma_remap_bilinear replaces cv2.remap(src, map, None, cv2.INTER_LINEAR)
+ * (border constant 0): warper.py:65 and optflow_registrator.py:45.
+ * src: (sh, sw, cn) of dtype; map: (dh, dw, 2) float32 absolute source
+ * coordinates; dst: (dh, dw, cn) of dtype.  cn is 1 or 2.  All dims < 32767. */
+int ma_remap_bilinear(ma_ctx* ctx, const void* src, int dtype, int cn, int sh, int sw,
+                      const float* map_xy, int dh, int dw, void* dst);
+
+/* Warper.warp() (warper.py:37-76): split image and flow into zero-padded
+ * (tile+2*overlap)^2 windows, map = float32(x_local - flow) per window
+ * (warper.py:55-60), cv2.remap per window, stitch the centres. */
+int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow,
+                  int tile, int overlap, void* out);
+
+/* OptFlowRegistrator._merge_flow_in_tiles / merge_two_flows
+ * (optflow_registrator.py:37-47,217-233): per window, out = flow2 if
+ * flow1.max()==0, flow1 if flow2.max()==0, else flow1 + remap(flow2, -flow1). */
+int ma_merge_flows_tiled(ma_ctx* ctx, const float* flow1, const float* flow2, int H, int W,
+                         int tile, int overlap, float* out);
+
+/* ---- pyramids -------------------------------------------------------------
+ * cv2.pyrDown(img) (optflow_registrator.py:194): dst is ((h+1)/2, (w+1)/2). */
+int ma_pyr_down(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst);
+/* cv2.pyrUp(flow * scale, dstsize=(dw, dh)) on a 2-channel float32 flow
+ * (optflow_registrator.py:140,150,164,169,212,214); the numpy pre-multiply
+ * (2, 4 or 1) is fused.  Requires |dw-2w| == dw%2 and |dh-2h| == dh%2. */
+int ma_pyr_up_flow(ma_ctx* ctx, const float* src, int h, int w, float scale, float* dst, int dh, int dw);
+
+/* ---- DOG -------------------------------------------------------------------
+ * img.max() etc. for the dog() shortcut (optflow_registrator.py:256). */
+int ma_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn_host, double* mx_host);
+/* The body of OptFlowRegistrator.dog (optflow_registrator.py:259-274):
+ * normalize(0,1,MINMAX,32F) -> GaussianBlur(k,k,low) & GaussianBlur(k,k,high)
+ * with k = low_sigma*8+1 -> hs-ls -> normalize(0,255,MINMAX,8U). */
+int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma,
+              uint8_t* dst);
+
+/* ---- NMI gate -----------------------------------------------------------------
+ * mi_tiled (similarity_scoring.py:27-50): normalized_mutual_info_score of two
+ * u8 label arrays over consecutive runs of `chunk` elements of the flattened
+ * arrays (chunk == 0 or chunk >= n: one score over everything).  Writes
+ * ceil(n/chunk) scores to scores_host (caller takes the mean). */
+int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk,
+              double* scores_host, int max_scores, int* n_scores);
+
+/* ---- "next" rows ------------------------------------------------
+ * np.maximum fold over z-planes (utils.py:92) and
+ * cv2.normalize(.., 0, 255, NORM_MINMAX, CV_8U) (utils.py:94). */
+int ma_max_project(ma_ctx* ctx, const void* planes, int dtype, int nz, size_t n, void* dst);
+int ma_normalize_minmax_u8(ma_ctx* ctx, const void* src, int dtype, size_t n, uint8_t* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MICROALIGNER_HIP_H */

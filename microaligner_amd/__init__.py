@@ -1,0 +1,14 @@
+"""microaligner_amd -- MI355X-native implementation of microaligner's optical-flow registration
+hot path (OptFlowRegistrator.register() + Warper.warp()) behind the reference's Python API.
+
+    from microaligner_amd import OptFlowRegistrator, Warper
+
+mirrors `from microaligner import OptFlowRegistrator, Warper` (microaligner/__init__.py:18-20).
+Compute runs in hand-written HIP kernels for gfx950 behind a C-ABI (include/microaligner_hip.h);
+there is no CPU fallback.
+"""
+from .optflow_reg import OptFlowRegistrator, TileFlowCalc, Warper, farneback, merge_two_flows
+from .shared_modules.utils import pad_to_shape
+
+__all__ = ["OptFlowRegistrator", "Warper", "TileFlowCalc", "farneback", "merge_two_flows", "pad_to_shape"]
+__version__ = "0.1.0"

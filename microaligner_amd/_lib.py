@@ -1,0 +1,87 @@
+"""ctypes binding of libmicroaligner_hip.so (the C-ABI declared in include/microaligner_hip.h).
+
+There is no CPU fallback: if the HIP library cannot be loaded the import of any
+compute entry point raises, loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmicroaligner_hip.so")
+
+MA_U8, MA_U16, MA_F32 = 0, 1, 2
+MA_OK, MA_EINVAL, MA_ENOMEM, MA_EHIP, MA_ENODEV = 0, -1, -2, -3, -4
+MA_FB_MULADD_FUSED = 1
+
+KERNEL_IDS = {"polyexp_m0": 0, "blur_v": 1, "blur_h_solve": 2, "warp": 3, "merge": 4, "pyr_down": 5,
+              "pyr_up": 6, "dog": 7, "nmi": 8, "other": 9}
+
+_vp, _i, _sz, _d, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_float
+
+# name -> (restype, argtypes): exactly the symbols of include/microaligner_hip.h
+SIGNATURES = {
+    "ma_version": (C.c_char_p, []),
+    "ma_last_error": (C.c_char_p, []),
+    "ma_device_count": (_i, [C.POINTER(_i)]),
+    "ma_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "ma_ctx_destroy": (None, [_vp]),
+    "ma_sync": (_i, [_vp]),
+    "ma_ctx_set_workspace_limit": (_i, [_vp, _sz]),
+    "ma_ctx_stream": (_vp, [_vp]),
+    "ma_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "ma_free": (_i, [_vp, _vp]),
+    "ma_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "ma_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "ma_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
+    "ma_memset": (_i, [_vp, _vp, _i, _sz]),
+    "ma_event_create": (_i, [_vp, C.POINTER(_vp)]),
+    "ma_event_destroy": (_i, [_vp, _vp]),
+    "ma_event_record": (_i, [_vp, _vp]),
+    "ma_event_elapsed_ms": (_i, [_vp, _vp, _vp, C.POINTER(_f)]),
+    "ma_profile_enable": (_i, [_vp, _i]),
+    "ma_profile_reset": (_i, [_vp]),
+    "ma_profile_get": (_i, [_vp, _i, C.POINTER(_d), C.POINTER(C.c_longlong), C.POINTER(_d)]),
+    "ma_farneback_tiled": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _d, _i, _vp]),
+    "ma_farneback_debug": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _d, _i, _vp, _vp, _vp, _vp]),
+    "ma_remap_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "ma_warp_tiled": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "ma_merge_flows_tiled": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ma_pyr_down": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "ma_pyr_up_flow": (_i, [_vp, _vp, _i, _i, _f, _vp, _i, _i]),
+    "ma_minmax": (_i, [_vp, _vp, _i, _sz, C.POINTER(_d), C.POINTER(_d)]),
+    "ma_dog_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ma_nmi_u8": (_i, [_vp, _vp, _vp, _sz, _sz, C.POINTER(_d), _i, C.POINTER(_i)]),
+    "ma_max_project": (_i, [_vp, _vp, _i, _i, _sz, _vp]),
+    "ma_normalize_minmax_u8": (_i, [_vp, _vp, _i, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and declare every prototype.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -m microaligner_amd.build). "
+            "microaligner_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the C-ABI lost a symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == MA_OK:
+        return
+    msg = load().ma_last_error().decode("utf-8", "replace")
+    if rc == MA_EINVAL:
+        raise ValueError(msg)
+    if rc == MA_ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(f"microaligner_hip error {rc}: {msg}")

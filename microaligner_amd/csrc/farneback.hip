@@ -1,0 +1,695 @@
+// Single-scale Farneback optical flow (cv2.calcOpticalFlowFarneback with levels=0,
+// poly_n=1, OPTFLOW_FARNEBACK_GAUSSIAN -- reference call site
+// microaligner/optflow_reg/flow_calc.py:33-44) batched over the zero-padded
+// overlapping windows TileFlowCalc cuts (flow_calc.py:59-98, slicer.py, stitcher.py).
+//
+// Pipeline per batch of windows (all fields planar f32, [window][plane][Ph][pitch]):
+//   fb_polyexp_m0     : image pair -> R0, R1 (5 planes each) and the first matrix field M (5 planes)
+//                       3x3 pre-blur (reflect-101) + 3x3 polynomial expansion (replicate), LDS staged.
+//   repeat iterations:
+//     fb_blur_v       : M -> V   win-tap Gaussian along y (replicate), register sliding window over LDS
+//     fb_blur_h_solve : V -> flow (2x2 solve in double) -> next M (UpdateMatrices fused), or, on the
+//                       last iteration, the centre crop of the window straight into the stitched flow.
+//
+// Arithmetic follows SURVEY.md Appendix A.1 operation by operation (compiled with
+// -ffp-contract=off), so results are bit-identical to oracle/ma_oracle.c.
+#include "ma_internal.h"
+
+#include <cmath>
+#include <cfloat>
+
+namespace {
+
+struct FbGeom {
+    MaTiling t;
+    int pitch;          // floats per plane row
+    int tile0;          // global index of the first window of this batch
+    size_t plane;       // floats per plane = Ph * pitch
+};
+
+struct PolyConsts {
+    float g0, g1, xg1, xxg1;
+    double ig11, ig03, ig33, ig55;
+};
+
+// planes per window in the workspace
+enum { PL_R0 = 0, PL_R1 = 5, PL_M = 10, PL_V = 15, PL_COUNT = 20 };
+
+__device__ __forceinline__ float* plane_ptr(float* ws, const FbGeom& g, int wl, int pl)
+{
+    return ws + ((size_t)wl * PL_COUNT + pl) * g.plane;
+}
+
+template <typename T>
+__device__ __forceinline__ float fetch_window(const T* img, const MaTiling& t, int oy, int ox, int ly, int lx)
+{
+    int y = oy + ly, x = ox + lx;
+    if ((unsigned)y < (unsigned)t.H && (unsigned)x < (unsigned)t.W) return (float)img[(size_t)y * t.W + x];
+    return 0.f;
+}
+
+__device__ __forceinline__ void window_origin(const MaTiling& t, int widx, int& oy, int& ox)
+{
+    if (t.T == 0) { oy = 0; ox = 0; return; }
+    int ty = widx / t.ntx, tx = widx - ty * t.ntx;
+    oy = ty * t.T - t.ov;
+    ox = tx * t.T - t.ov;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: pre-blur + polynomial expansion of both images + first UpdateMatrices (flow == 0)
+// ---------------------------------------------------------------------------------------------
+constexpr int K1_TX = 64, K1_TY = 16, K1_THREADS = 256;
+
+__device__ __forceinline__ void update_matrices_px(const float r0[5], float r2, float r3, float r4, float r5,
+                                                   float r6, bool inside, float dx, float dy, int x, int y,
+                                                   int w, int h, float out[5])
+{
+    // A.1 step 3; r2..r6 are the (bilinearly sampled) R1 values when `inside`
+    if (inside) {
+        r4 = (r0[2] + r4) * 0.5f;
+        r5 = (r0[3] + r5) * 0.5f;
+        r6 = (r0[4] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = r0[2];
+        r5 = r0[3];
+        r6 = r0[4] * 0.5f;
+    }
+    r2 = (r0[0] - r2) * 0.5f;
+    r3 = (r0[1] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    const int BORDER = 5;
+    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+        const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+        float scale = (x < BORDER ? border[x] : 1.f) * (x >= w - BORDER ? border[w - x - 1] : 1.f) *
+                      (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    out[0] = r4 * r4 + r6 * r6;
+    out[1] = (r4 + r5) * r6;
+    out[2] = r5 * r5 + r6 * r6;
+    out[3] = r4 * r2 + r6 * r3;
+    out[4] = r6 * r2 + r5 * r3;
+}
+
+template <typename T>
+__global__ __launch_bounds__(K1_THREADS) void fb_polyexp_m0(const T* __restrict__ prev, const T* __restrict__ next,
+                                                            FbGeom g, PolyConsts pc, float* __restrict__ ws)
+{
+    constexpr int RW = K1_TX + 4, RH = K1_TY + 4;   // raw tile
+    constexpr int TW = K1_TX + 2;                   // row-blurred / blurred / vertical-pass tiles
+    __shared__ float raw[RH][RW];
+    __shared__ float tb[RH][TW];
+    __shared__ float bl[K1_TY + 2][TW];
+    __shared__ float vt[3][K1_TY][TW];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * K1_TX, y0 = blockIdx.y * K1_TY;
+    const int wl = blockIdx.z;
+    const int Ph = g.t.Ph, Pw = g.t.Pw;
+    int oy, ox;
+    window_origin(g.t, g.tile0 + wl, oy, ox);
+
+    const int lx = tid & 63, lyg = tid >> 6;  // output mapping: column lx, rows lyg*4 .. lyg*4+3
+    float r0v[4][5];
+
+    for (int img = 0; img < 2; img++) {
+        const T* src = img == 0 ? prev : next;
+        // 1. raw tile at virtual coordinates (reflect-101 of the window), zero outside the image
+        for (int i = tid; i < RH * RW; i += K1_THREADS) {
+            int j = i / RW, c = i - j * RW;
+            int ty = d_reflect101(y0 - 2 + j, Ph), tx = d_reflect101(x0 - 2 + c, Pw);
+            raw[j][c] = fetch_window(src, g.t, oy, ox, ty, tx);
+        }
+        __syncthreads();
+        // 2. horizontal [1/4 1/2 1/4] at clamped columns
+        for (int i = tid; i < RH * TW; i += K1_THREADS) {
+            int j = i / TW, c = i - j * TW;
+            int cx = d_clamp(x0 - 1 + c, 0, Pw - 1) - (x0 - 2);
+            cx = d_clamp(cx, 1, RW - 2);  // only out-of-window rows of a partial block can hit this
+            tb[j][c] = raw[j][cx] * 0.5f + (raw[j][cx - 1] + raw[j][cx + 1]) * 0.25f;
+        }
+        __syncthreads();
+        // 3. vertical [1/4 1/2 1/4] at clamped rows -> blurred image (replicate semantics for step 4/5)
+        for (int i = tid; i < (K1_TY + 2) * TW; i += K1_THREADS) {
+            int j = i / TW, c = i - j * TW;
+            int cy = d_clamp(y0 - 1 + j, 0, Ph - 1) - (y0 - 2);
+            cy = d_clamp(cy, 1, RH - 2);
+            bl[j][c] = tb[cy][c] * 0.5f + (tb[cy - 1][c] + tb[cy + 1][c]) * 0.25f;
+        }
+        __syncthreads();
+        // 4. vertical part of the polynomial expansion (float)
+        for (int i = tid; i < K1_TY * TW; i += K1_THREADS) {
+            int j = i / TW, c = i - j * TW;
+            float up = bl[j][c], ce = bl[j + 1][c], dn = bl[j + 2][c];
+            float p = up + dn;
+            float row0 = ce * pc.g0;
+            vt[0][j][c] = row0 + pc.g1 * p;
+            vt[1][j][c] = 0.f + pc.xg1 * (dn - up);
+            vt[2][j][c] = 0.f + pc.xxg1 * p;
+        }
+        __syncthreads();
+        // 5. horizontal part (double accumulators where OpenCV has them) -> R
+#pragma unroll
+        for (int rr = 0; rr < 4; rr++) {
+            const int j = lyg * 4 + rr;
+            const int y = y0 + j, x = x0 + lx;
+            const int c = lx + 1;
+            float a0m = vt[0][j][c - 1], a0 = vt[0][j][c], a0p = vt[0][j][c + 1];
+            float a1m = vt[1][j][c - 1], a1 = vt[1][j][c], a1p = vt[1][j][c + 1];
+            float a2m = vt[2][j][c - 1], a2 = vt[2][j][c], a2p = vt[2][j][c + 1];
+            double b1 = (double)(a0 * pc.g0), b3 = (double)(a1 * pc.g0), b5 = (double)(a2 * pc.g0);
+            double tg = (double)(a0p + a0m);
+            b1 += tg * (double)pc.g1;
+            double b4 = 0.0 + tg * (double)pc.xxg1;
+            double b2 = 0.0 + (double)((a0p - a0m) * pc.xg1);
+            b3 += (double)((a1p + a1m) * pc.g1);
+            double b6 = 0.0 + (double)((a1p - a1m) * pc.xg1);
+            b5 += (double)((a2p + a2m) * pc.g1);
+            float R[5];
+            R[1] = (float)(b2 * pc.ig11);
+            R[0] = (float)(b3 * pc.ig11);
+            R[3] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+            R[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+            R[4] = (float)(b6 * pc.ig55);
+            const bool ok = y < Ph && x < Pw;
+            if (ok) {
+                float* dst = plane_ptr(ws, g, wl, img == 0 ? PL_R0 : PL_R1) + (size_t)y * g.pitch + x;
+#pragma unroll
+                for (int k = 0; k < 5; k++) dst[k * g.plane] = R[k];
+            }
+            if (img == 0) {
+#pragma unroll
+                for (int k = 0; k < 5; k++) r0v[rr][k] = R[k];
+            } else if (ok) {
+                // first UpdateMatrices with flow == 0: the bilinear sample degenerates to R1 itself
+                const bool inside = x < Pw - 1 && y < Ph - 1;
+                float Mv[5];
+                update_matrices_px(r0v[rr], R[0], R[1], R[2], R[3], R[4], inside, 0.f, 0.f, x, y, Pw, Ph, Mv);
+                float* dst = plane_ptr(ws, g, wl, PL_M) + (size_t)y * g.pitch + x;
+#pragma unroll
+                for (int k = 0; k < 5; k++) dst[k * g.plane] = Mv[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: vertical window blur  M -> V   (one plane per blockIdx.z)
+// Lanes run along x; each thread owns one column and R consecutive output rows, sliding a register
+// window over an LDS-staged column strip:  s = c*k0;  s = (dn_i + up_i)*k_i + s  for i = 1..m.
+// ---------------------------------------------------------------------------------------------
+template <int R, int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW) void fb_blur_v(FbGeom g, int m, const float* __restrict__ taps,
+                                                     float* __restrict__ ws)
+{
+    extern __shared__ float lds[];  // [(NW*R + 2m)][64]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * (NW * R);
+    const int wl = blockIdx.z / 5, ch = blockIdx.z - wl * 5;
+    const int Ph = g.t.Ph, Pw = g.t.Pw;
+    const float* src = plane_ptr(ws, g, wl, PL_M + ch);
+    float* dst = plane_ptr(ws, g, wl, PL_V + ch);
+
+    const int rows = NW * R + 2 * m;
+    const int xc = min(x0 + lane, Pw - 1);
+    for (int j = w; j < rows; j += NW) {
+        int y = d_clamp(y0 - m + j, 0, Ph - 1);
+        lds[j * 64 + lane] = src[(size_t)y * g.pitch + xc];
+    }
+    __syncthreads();
+
+    const int jb = m + w * R;  // LDS row of this thread's first output row
+    float acc[R], P[R], Q[R];
+    const float k0 = taps[0];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = lds[(jb + r) * 64 + lane] * k0;
+#pragma unroll
+    for (int o = 1; o <= R; o++) P[o % R] = lds[(jb + o) * 64 + lane];
+#pragma unroll
+    for (int o = -1; o <= R - 2; o++) Q[(o + R) % R] = lds[(jb + o) * 64 + lane];
+
+    for (int i0 = 0; i0 < m; i0 += R) {
+#pragma unroll
+        for (int ii = 0; ii < R; ii++) {
+            const int i = i0 + ii + 1;
+            if (i <= m) {
+                const float ki = taps[i];
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    acc[r] = d_muladd<FUSED>(P[(r + ii + 1) % R] + Q[((r - ii - 1) % R + R) % R], ki, acc[r]);
+                if (i < m) {
+                    P[(ii + 1) % R] = lds[(jb + i + R) * 64 + lane];
+                    Q[((-ii - 2) % R + R) % R] = lds[(jb - i - 1) * 64 + lane];
+                }
+            }
+        }
+    }
+    const int x = x0 + lane;
+    if (x < Pw) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            int y = y0 + w * R + r;
+            if (y < Ph) dst[(size_t)y * g.pitch + x] = acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: horizontal window blur of V (5 planes) + 2x2 solve (double) + UpdateMatrices / final store.
+// Lanes run along y (one row each) so the register window slides along x; results are transposed
+// through LDS so that all global traffic (R0, R1 gather, M / flow stores) is coalesced along x.
+// Block: 64 rows x (NW*R) columns.
+// ---------------------------------------------------------------------------------------------
+template <int R, int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW) void fb_blur_h_solve(FbGeom g, int m, const float* __restrict__ taps,
+                                                           float* __restrict__ ws, int last,
+                                                           float* __restrict__ flow_out)
+{
+    extern __shared__ float lds[];
+    constexpr int TXW = NW * R;           // output columns per block
+    constexpr int NT = 64 * NW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const int x0 = blockIdx.x * TXW, y0 = blockIdx.y * 64;
+    const int wl = blockIdx.z;
+    const int Ph = g.t.Ph, Pw = g.t.Pw;
+    const int cols = TXW + 2 * m;
+    const int lp = cols | 1;              // odd LDS pitch: lanes (rows) hit distinct banks
+
+    float hs[5][R];
+    const float k0 = taps[0];
+#pragma unroll
+    for (int ch = 0; ch < 5; ch++) {
+        const float* src = plane_ptr(ws, g, wl, PL_V + ch);
+        // stage rows y0..y0+63, columns x0-m .. x0+TXW+m-1 (replicate), coalesced along x
+        for (int i = tid; i < 64 * cols; i += NT) {
+            int j = i / cols, c = i - j * cols;
+            int y = min(y0 + j, Ph - 1);
+            int x = d_clamp(x0 - m + c, 0, Pw - 1);
+            lds[j * lp + c] = src[(size_t)y * g.pitch + x];
+        }
+        __syncthreads();
+        const float* row = lds + lane * lp;
+        const int cb = m + w * R;
+        float acc[R], P[R], Q[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = row[cb + r] * k0;
+#pragma unroll
+        for (int o = 1; o <= R; o++) P[o % R] = row[cb + o];
+#pragma unroll
+        for (int o = -1; o <= R - 2; o++) Q[(o + R) % R] = row[cb + o];
+        for (int i0 = 0; i0 < m; i0 += R) {
+#pragma unroll
+            for (int ii = 0; ii < R; ii++) {
+                const int i = i0 + ii + 1;
+                if (i <= m) {
+                    const float ki = taps[i];
+#pragma unroll
+                    for (int r = 0; r < R; r++)
+                        acc[r] = d_muladd<FUSED>(Q[((r - ii - 1) % R + R) % R] + P[(r + ii + 1) % R], ki, acc[r]);
+                    if (i < m) {
+                        P[(ii + 1) % R] = row[cb + i + R];
+                        Q[((-ii - 2) % R + R) % R] = row[cb - i - 1];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) hs[ch][r] = acc[r];
+        __syncthreads();
+    }
+
+    // transpose through LDS in two halves of 32 rows: tb[ch][32][TXW+1]
+    constexpr int TP = TXW + 1;
+    int oy, ox;
+    window_origin(g.t, g.tile0 + wl, oy, ox);
+    const float* R0p = plane_ptr(ws, g, wl, PL_R0);
+    const float* R1p = plane_ptr(ws, g, wl, PL_R1);
+    float* Mp = plane_ptr(ws, g, wl, PL_M);
+    for (int half = 0; half < 2; half++) {
+        if ((lane >> 5) == half) {
+#pragma unroll
+            for (int ch = 0; ch < 5; ch++)
+#pragma unroll
+                for (int r = 0; r < R; r++) lds[(ch * 32 + (lane & 31)) * TP + w * R + r] = hs[ch][r];
+        }
+        __syncthreads();
+        for (int p = tid; p < 32 * TXW; p += NT) {
+            const int rh = p / TXW, c = p - rh * TXW;
+            const int y = y0 + half * 32 + rh, x = x0 + c;
+            if (y < Ph && x < Pw) {
+                double g11 = lds[(0 * 32 + rh) * TP + c], g12 = lds[(1 * 32 + rh) * TP + c],
+                       g22 = lds[(2 * 32 + rh) * TP + c], h1 = lds[(3 * 32 + rh) * TP + c],
+                       h2 = lds[(4 * 32 + rh) * TP + c];
+                double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                float dx = (float)((g11 * h2 - g12 * h1) * idet);
+                float dy = (float)((g22 * h1 - g12 * h2) * idet);
+                if (last) {
+                    // centre crop of the window -> stitched flow (stitcher.py:62-65)
+                    bool keep;
+                    if (g.t.T == 0) keep = true;
+                    else keep = y >= g.t.ov && y < g.t.ov + g.t.T && x >= g.t.ov && x < g.t.ov + g.t.T;
+                    int iy = oy + y, ix = ox + x;
+                    if (keep && iy < g.t.H && ix < g.t.W) {
+                        float2 v = make_float2(dx, dy);
+                        reinterpret_cast<float2*>(flow_out)[(size_t)iy * g.t.W + ix] = v;
+                    }
+                } else {
+                    // UpdateMatrices (A.1 step 3) at this pixel
+                    const size_t pix = (size_t)y * g.pitch + x;
+                    float r0[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) r0[k] = R0p[k * g.plane + pix];
+                    float fx = (float)x + dx, fy = (float)y + dy;
+                    int x1 = d_cvfloor(fx), y1 = d_cvfloor(fy);
+                    fx -= (float)x1; fy -= (float)y1;
+                    float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+                    const bool inside = (unsigned)x1 < (unsigned)(Pw - 1) && (unsigned)y1 < (unsigned)(Ph - 1);
+                    if (inside) {
+                        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy,
+                              a11 = fx * fy;
+                        const float* q = R1p + (size_t)y1 * g.pitch + x1;
+#pragma unroll
+                        for (int k = 0; k < 5; k++) {
+                            const float* qk = q + k * g.plane;
+                            r[k] = a00 * qk[0] + a01 * qk[1] + a10 * qk[g.pitch] + a11 * qk[g.pitch + 1];
+                        }
+                    }
+                    float Mv[5];
+                    update_matrices_px(r0, r[0], r[1], r[2], r[3], r[4], inside, dx, dy, x, y, Pw, Ph, Mv);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) Mp[k * g.plane + pix] = Mv[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fallback kernels for windows whose halo does not fit LDS (winsize > ~450): plain per-pixel loops.
+// ---------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ void fb_blur_v_simple(FbGeom g, int m, const float* __restrict__ taps, float* __restrict__ ws)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int wl = blockIdx.z / 5, ch = blockIdx.z - wl * 5;
+    if (x >= g.t.Pw) return;
+    const float* src = plane_ptr(ws, g, wl, PL_M + ch);
+    float* dst = plane_ptr(ws, g, wl, PL_V + ch);
+    float s = src[(size_t)y * g.pitch + x] * taps[0];
+    for (int i = 1; i <= m; i++) {
+        float dn = src[(size_t)min(y + i, g.t.Ph - 1) * g.pitch + x];
+        float up = src[(size_t)max(y - i, 0) * g.pitch + x];
+        s = d_muladd<FUSED>(dn + up, taps[i], s);
+    }
+    dst[(size_t)y * g.pitch + x] = s;
+}
+
+template <bool FUSED>
+__global__ void fb_blur_h_solve_simple(FbGeom g, int m, const float* __restrict__ taps, float* __restrict__ ws,
+                                       int last, float* __restrict__ flow_out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    const int wl = blockIdx.z;
+    const int Ph = g.t.Ph, Pw = g.t.Pw;
+    if (x >= Pw) return;
+    float hsum[5];
+    for (int ch = 0; ch < 5; ch++) {
+        const float* src = plane_ptr(ws, g, wl, PL_V + ch) + (size_t)y * g.pitch;
+        float s = src[x] * taps[0];
+        for (int i = 1; i <= m; i++) s = d_muladd<FUSED>(src[max(x - i, 0)] + src[min(x + i, Pw - 1)], taps[i], s);
+        hsum[ch] = s;
+    }
+    double g11 = hsum[0], g12 = hsum[1], g22 = hsum[2], h1 = hsum[3], h2 = hsum[4];
+    double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+    float dx = (float)((g11 * h2 - g12 * h1) * idet);
+    float dy = (float)((g22 * h1 - g12 * h2) * idet);
+    int oy, ox;
+    window_origin(g.t, g.tile0 + wl, oy, ox);
+    if (last) {
+        bool keep = g.t.T == 0 || (y >= g.t.ov && y < g.t.ov + g.t.T && x >= g.t.ov && x < g.t.ov + g.t.T);
+        int iy = oy + y, ix = ox + x;
+        if (keep && iy < g.t.H && ix < g.t.W)
+            reinterpret_cast<float2*>(flow_out)[(size_t)iy * g.t.W + ix] = make_float2(dx, dy);
+        return;
+    }
+    const float* R0p = plane_ptr(ws, g, wl, PL_R0);
+    const float* R1p = plane_ptr(ws, g, wl, PL_R1);
+    float* Mp = plane_ptr(ws, g, wl, PL_M);
+    const size_t pix = (size_t)y * g.pitch + x;
+    float r0[5];
+    for (int k = 0; k < 5; k++) r0[k] = R0p[k * g.plane + pix];
+    float fx = (float)x + dx, fy = (float)y + dy;
+    int x1 = d_cvfloor(fx), y1 = d_cvfloor(fy);
+    fx -= (float)x1; fy -= (float)y1;
+    float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool inside = (unsigned)x1 < (unsigned)(Pw - 1) && (unsigned)y1 < (unsigned)(Ph - 1);
+    if (inside) {
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const float* q = R1p + (size_t)y1 * g.pitch + x1;
+        for (int k = 0; k < 5; k++) {
+            const float* qk = q + k * g.plane;
+            r[k] = a00 * qk[0] + a01 * qk[1] + a10 * qk[g.pitch] + a11 * qk[g.pitch + 1];
+        }
+    }
+    float Mv[5];
+    update_matrices_px(r0, r[0], r[1], r[2], r[3], r[4], inside, dx, dy, x, y, Pw, Ph, Mv);
+    for (int k = 0; k < 5; k++) Mp[k * g.plane + pix] = Mv[k];
+}
+
+// planar workspace -> user buffers (debug variant)
+__global__ void fb_copy_planes(FbGeom g, const float* __restrict__ ws, int pl, float* __restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, k = blockIdx.z;
+    if (x >= g.t.Pw) return;
+    out[((size_t)k * g.t.Ph + y) * g.t.Pw + x] = ws[((size_t)pl + k) * g.plane + (size_t)y * g.pitch + x];
+}
+
+// ---- host side ------------------------------------------------------------------------------
+
+// hal::Cholesky64f-style SPD solve, as used by Mat::inv(DECOMP_CHOLESKY) (A.1 step 2)
+bool chol_inverse6(double* A, double* b)
+{
+    const int m = 6, n = 6;
+    for (int i = 0; i < m; i++) {
+        int j;
+        for (j = 0; j < i; j++) {
+            double s = A[i * m + j];
+            for (int k = 0; k < j; k++) s -= A[i * m + k] * A[j * m + k];
+            A[i * m + j] = s * A[j * m + j];
+        }
+        double s = A[i * m + i];
+        for (int k = 0; k < j; k++) { double t = A[i * m + k]; s -= t * t; }
+        if (s < DBL_EPSILON) return false;
+        A[i * m + i] = 1. / std::sqrt(s);
+    }
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < n; j++) {
+            double s = b[i * n + j];
+            for (int k = 0; k < i; k++) s -= A[i * m + k] * b[k * n + j];
+            b[i * n + j] = s * A[i * m + i];
+        }
+    for (int i = m - 1; i >= 0; i--)
+        for (int j = 0; j < n; j++) {
+            double s = b[i * n + j];
+            for (int k = m - 1; k > i; k--) s -= A[k * m + i] * b[k * n + j];
+            b[i * n + j] = s * A[i * m + i];
+        }
+    return true;
+}
+
+bool make_poly_consts(double sigma, PolyConsts* pc)
+{
+    const int n = 1;
+    float gb[3], xgb[3], xxgb[3];
+    float *gk = gb + n, *xg = xgb + n, *xxg = xxgb + n;
+    if (sigma < FLT_EPSILON) sigma = n * 0.3;
+    double s = 0.;
+    for (int x = -n; x <= n; x++) {
+        gk[x] = (float)std::exp(-x * x / (2 * sigma * sigma));
+        s += gk[x];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) {
+        gk[x] = (float)(gk[x] * s);
+        xg[x] = (float)(x * gk[x]);
+        xxg[x] = (float)(x * x * gk[x]);
+    }
+    double G[36] = {0}, I6[36] = {0};
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            G[0] += gk[y] * gk[x];
+            G[7] += gk[y] * gk[x] * x * x;
+            G[21] += gk[y] * gk[x] * x * x * x * x;
+            G[35] += gk[y] * gk[x] * x * x * y * y;
+        }
+    G[14] = G[3] = G[4] = G[18] = G[24] = G[7];
+    G[28] = G[21];
+    G[22] = G[27] = G[35];
+    for (int i = 0; i < 6; i++) I6[i * 6 + i] = 1.;
+    if (!chol_inverse6(G, I6)) return false;
+    pc->g0 = gk[0]; pc->g1 = gk[1]; pc->xg1 = xg[1]; pc->xxg1 = xxg[1];
+    pc->ig11 = I6[7]; pc->ig03 = I6[3]; pc->ig33 = I6[21]; pc->ig55 = I6[35];
+    return true;
+}
+
+void make_window_taps(int winsize, std::vector<float>& k)
+{
+    int m = winsize / 2;
+    k.resize(m + 1);
+    double sigma = m * 0.3, s = 1;
+    k[0] = (float)s;
+    for (int i = 1; i <= m; i++) {
+        float t = (float)std::exp(-i * i / (2 * sigma * sigma));
+        k[i] = t;
+        s += t * 2;
+    }
+    s = 1. / s;
+    for (int i = 0; i <= m; i++) k[i] = (float)(k[i] * s);
+}
+
+constexpr int BV_R = 16, BV_NW = 4;   // fb_blur_v: 64 columns x 64 rows per block
+constexpr int BH_R = 8, BH_NW = 8;    // fb_blur_h_solve: 64 rows x 64 columns per block
+constexpr size_t LDS_MAX = 160 * 1024;
+
+template <typename T, bool FUSED>
+int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, const PolyConsts& pc, int m,
+              const float* taps, int iters, float* flow_out)
+{
+    float* ws = (float*)ctx->ws;
+    const int Ph = g.t.Ph, Pw = g.t.Pw;
+    const double px = (double)nwin * Ph * Pw;
+    {
+        MaProfScope ps(ctx, MA_K_POLYEXP_M0, px);
+        dim3 grid((Pw + K1_TX - 1) / K1_TX, (Ph + K1_TY - 1) / K1_TY, nwin);
+        hipLaunchKernelGGL((fb_polyexp_m0<T>), grid, dim3(K1_THREADS), 0, ctx->stream, prev, next, g, pc, ws);
+    }
+    const size_t lds_v = (size_t)(BV_NW * BV_R + 2 * m) * 64 * sizeof(float);
+    const int colsh = BH_NW * BH_R + 2 * m;
+    size_t lds_h = (size_t)64 * (colsh | 1) * sizeof(float);
+    const size_t lds_t = (size_t)5 * 32 * (BH_NW * BH_R + 1) * sizeof(float);
+    if (lds_t > lds_h) lds_h = lds_t;
+    const bool fast = m >= 1 && lds_v <= LDS_MAX && lds_h <= LDS_MAX;
+    for (int it = 0; it < iters; it++) {
+        const int last = it == iters - 1;
+        if (fast) {
+            {
+                MaProfScope ps(ctx, MA_K_BLUR_V, px);
+                dim3 grid((Pw + 63) / 64, (Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R), nwin * 5);
+                hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), grid, dim3(64 * BV_NW), lds_v, ctx->stream, g, m,
+                                   taps, ws);
+            }
+            {
+                MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px);
+                dim3 grid((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R), (Ph + 63) / 64, nwin);
+                hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED>), grid, dim3(64 * BH_NW), lds_h, ctx->stream,
+                                   g, m, taps, ws, last, flow_out);
+            }
+        } else {
+            {
+                MaProfScope ps(ctx, MA_K_BLUR_V, px);
+                dim3 grid((Pw + 255) / 256, Ph, nwin * 5);
+                hipLaunchKernelGGL((fb_blur_v_simple<FUSED>), grid, dim3(256), 0, ctx->stream, g, m, taps, ws);
+            }
+            {
+                MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px);
+                dim3 grid((Pw + 255) / 256, Ph, nwin);
+                hipLaunchKernelGGL((fb_blur_h_solve_simple<FUSED>), grid, dim3(256), 0, ctx->stream, g, m, taps, ws,
+                                   last, flow_out);
+            }
+        }
+    }
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+int get_taps(ma_ctx* ctx, int winsize, const float** out)
+{
+    std::vector<float> k;
+    make_window_taps(winsize, k);
+    return ma_const_table(ctx, ((uint64_t)1 << 56) | (uint64_t)winsize, k.data(), k.size(), out);
+}
+
+int farneback_impl(ma_ctx* ctx, const void* prev, const void* next, int dtype, int H, int W, int tile, int overlap,
+                   int winsize, int iterations, int poly_n, double poly_sigma, int flags, float* flow_out,
+                   float* R0_out, float* R1_out, float* M0_out)
+{
+    MA_REQUIRE(ctx && prev && next && flow_out, "NULL argument");
+    MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
+    MA_REQUIRE(H > 0 && W > 0, "image must be non-empty");
+    MA_REQUIRE(tile >= 0 && overlap >= 0, "tile/overlap must be >= 0");
+    MA_REQUIRE(winsize >= 1, "winsize must be >= 1");
+    MA_REQUIRE(iterations >= 1, "iterations must be >= 1");
+    MA_REQUIRE(poly_n == 1, "only poly_n == 1 is supported (the value microaligner passes)");
+    MA_HIP(hipSetDevice(ctx->device));
+
+    PolyConsts pc;
+    if (!make_poly_consts(poly_sigma, &pc)) { ma_set_error("polynomial-expansion Gram matrix is singular"); return MA_EINVAL; }
+    const float* taps = nullptr;
+    MA_TRY(get_taps(ctx, winsize, &taps));
+    const int m = winsize / 2;
+
+    FbGeom g;
+    g.t = ma_make_tiling(H, W, tile, overlap);
+    g.pitch = (int)ma_align_up((size_t)g.t.Pw, 64);
+    g.plane = (size_t)g.t.Ph * g.pitch;
+    const int nwin_total = g.t.ntx * g.t.nty;
+    const size_t per_win = g.plane * PL_COUNT * sizeof(float);
+    MA_REQUIRE(per_win <= ctx->ws_limit, "one window does not fit the workspace limit");
+    int batch = (int)(ctx->ws_limit / per_win);
+    if (batch > nwin_total) batch = nwin_total;
+    if ((long long)batch * 5 > 65535) batch = 65535 / 5;  // gridDim.z
+    MA_TRY(ma_ws_reserve(ctx, per_win * batch));
+    const bool fused = (flags & MA_FB_MULADD_FUSED) != 0;
+
+    for (int t0 = 0; t0 < nwin_total; t0 += batch) {
+        int n = nwin_total - t0 < batch ? nwin_total - t0 : batch;
+        g.tile0 = t0;
+        int rc;
+#define RUN(TYPE)                                                                                           \
+    rc = fused ? run_batch<TYPE, true>(ctx, (const TYPE*)prev, (const TYPE*)next, g, n, pc, m, taps, iterations, flow_out) \
+               : run_batch<TYPE, false>(ctx, (const TYPE*)prev, (const TYPE*)next, g, n, pc, m, taps, iterations, flow_out)
+        if (dtype == MA_U8) { RUN(uint8_t); }
+        else if (dtype == MA_U16) { RUN(uint16_t); }
+        else { RUN(float); }
+#undef RUN
+        if (rc != MA_OK) return rc;
+    }
+    if (R0_out || R1_out || M0_out) {
+        // debug dump is only meaningful for iterations == 1 semantics of M; R0/R1 are always valid
+        dim3 grid((g.t.Pw + 255) / 256, g.t.Ph, 5);
+        float* ws = (float*)ctx->ws;
+        if (R0_out) hipLaunchKernelGGL(fb_copy_planes, grid, dim3(256), 0, ctx->stream, g, ws, (int)PL_R0, R0_out);
+        if (R1_out) hipLaunchKernelGGL(fb_copy_planes, grid, dim3(256), 0, ctx->stream, g, ws, (int)PL_R1, R1_out);
+        if (M0_out) hipLaunchKernelGGL(fb_copy_planes, grid, dim3(256), 0, ctx->stream, g, ws, (int)PL_M, M0_out);
+        MA_HIP(hipGetLastError());
+    }
+    return MA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int ma_farneback_tiled(ma_ctx* ctx, const void* prev, const void* next, int dtype, int H, int W, int tile,
+                       int overlap, int winsize, int iterations, int poly_n, double poly_sigma, int flags,
+                       float* flow_out)
+{
+    return farneback_impl(ctx, prev, next, dtype, H, W, tile, overlap, winsize, iterations, poly_n, poly_sigma,
+                          flags, flow_out, nullptr, nullptr, nullptr);
+}
+
+int ma_farneback_debug(ma_ctx* ctx, const void* prev, const void* next, int dtype, int H, int W, int winsize,
+                       int iterations, double poly_sigma, int flags, float* flow_out, float* R0_planar,
+                       float* R1_planar, float* M0_planar)
+{
+    return farneback_impl(ctx, prev, next, dtype, H, W, 0, 0, winsize, iterations, 1, poly_sigma, flags, flow_out,
+                          R0_planar, R1_planar, M0_planar);
+}
+
+} // extern "C"

@@ -1,0 +1,141 @@
+// The mutual-information accept/reject gate: sklearn.metrics.normalized_mutual_info_score on u8
+// label images, chunked as mi_tiled does (microaligner/shared_modules/similarity_scoring.py:27-50).
+// Labels are pixel values, so the contingency matrix is a 256x256 joint histogram (exact integer
+// counts); the score follows sklearn's formula in f64.
+#include "ma_internal.h"
+
+#include <cfloat>
+
+namespace {
+
+// grid: (blocks per chunk, chunks).  Global atomics into the chunk's 256 KiB histogram (L2 resident).
+__global__ __launch_bounds__(256) void joint_hist_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                         size_t n, size_t chunk, unsigned* __restrict__ hist)
+{
+    const size_t c0 = (size_t)blockIdx.y * chunk;
+    const size_t c1 = c0 + chunk < n ? c0 + chunk : n;
+    unsigned* hh = hist + (size_t)blockIdx.y * 65536;
+    for (size_t i = c0 + (size_t)blockIdx.x * 256 + threadIdx.x; i < c1; i += (size_t)gridDim.x * 256)
+        atomicAdd(&hh[(unsigned)a[i] * 256u + b[i]], 1u);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// one block per chunk
+__global__ __launch_bounds__(256) void nmi_reduce_kernel(const unsigned* __restrict__ hist, size_t n, size_t chunk,
+                                                         double* __restrict__ scores)
+{
+    __shared__ unsigned pa[256];
+    __shared__ unsigned long long pb_s[256];
+    __shared__ double red[4];
+    __shared__ int cnt[2];
+    const unsigned* hh = hist + (size_t)blockIdx.x * 65536;
+    const int j = threadIdx.x, lane = j & 63, w = j >> 6;
+    const size_t c0 = (size_t)blockIdx.x * chunk;
+    const double N = (double)((c0 + chunk < n ? c0 + chunk : n) - c0);
+
+    pa[j] = 0;
+    if (j < 2) cnt[j] = 0;
+    __syncthreads();
+    unsigned long long pbj = 0;
+    for (int r = 0; r < 256; r++) {
+        unsigned v = hh[r * 256 + j];
+        pbj += v;
+        unsigned s = v;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+        if (lane == 0) atomicAdd(&pa[r], s);
+    }
+    pb_s[j] = pbj;
+    __syncthreads();
+    if (pa[j] > 0) atomicAdd(&cnt[0], 1);
+    if (pbj > 0) atomicAdd(&cnt[1], 1);
+    __syncthreads();
+    const int ca = cnt[0], cb = cnt[1];
+    if (ca == 1 && cb == 1) {  // both label sets have a single value
+        if (j == 0) scores[blockIdx.x] = 1.0;
+        return;
+    }
+    const double logN = log(N);
+    double mi = 0.0;
+    if (pbj > 0) {
+        for (int r = 0; r < 256; r++) {
+            unsigned nij = hh[r * 256 + j];
+            if (nij) {
+                double log_nm = log((double)nij);
+                double nm = (double)nij / N;
+                double outer = (double)((long long)pa[r] * (long long)pbj);
+                double log_outer = -log(outer) + logN + logN;
+                double term = nm * (log_nm - logN) + nm * log_outer;
+                if (fabs(term) < DBL_EPSILON) term = 0.0;
+                mi += term;
+            }
+        }
+    }
+    // entropies: thread j contributes label j of each side
+    double ha = 0.0, hb = 0.0;
+    if (pa[j] > 0) ha = ((double)pa[j] / N) * (log((double)pa[j]) - logN);
+    if (pbj > 0) hb = ((double)pbj / N) * (log((double)pbj) - logN);
+
+    double vals[3] = {mi, ha, hb}, tot[3];
+    for (int k = 0; k < 3; k++) {
+        double s = wave_sum(vals[k]);
+        if (lane == 0) red[w] = s;
+        __syncthreads();
+        tot[k] = red[0] + red[1] + red[2] + red[3];
+        __syncthreads();
+    }
+    if (j == 0) {
+        double m = tot[0] < 0 ? 0.0 : tot[0];
+        double score;
+        if (fabs(m) < DBL_EPSILON) score = 0.0;
+        else {
+            double h_a = ca == 1 ? 0.0 : -tot[1], h_b = cb == 1 ? 0.0 : -tot[2];
+            double norm = 0.5 * (h_a + h_b);
+            if (norm < DBL_EPSILON) norm = DBL_EPSILON;
+            score = m / norm;
+        }
+        scores[blockIdx.x] = score;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk, double* scores_host,
+              int max_scores, int* n_scores)
+{
+    MA_REQUIRE(ctx && a && b && scores_host && n_scores, "NULL argument");
+    MA_REQUIRE(n > 0, "empty arrays");
+    if (chunk == 0 || chunk > n) chunk = n;
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    MA_REQUIRE(nchunks <= 65535 && (size_t)max_scores >= nchunks, "scores buffer too small");
+    MA_REQUIRE(chunk < ((size_t)1 << 32), "chunk must be < 2^32 elements");
+    MA_HIP(hipSetDevice(ctx->device));
+    const size_t hist_bytes = nchunks * 65536 * sizeof(unsigned);
+    const size_t total = hist_bytes + nchunks * sizeof(double);
+    MA_TRY(ma_ws_reserve(ctx, total));
+    MA_TRY(ma_pinned_reserve(ctx, nchunks * sizeof(double)));
+    unsigned* hist = (unsigned*)ctx->ws;
+    double* scores = (double*)((char*)ctx->ws + hist_bytes);
+    {
+        MaProfScope ps(ctx, MA_K_NMI, (double)n);
+        MA_HIP(hipMemsetAsync(hist, 0, hist_bytes, ctx->stream));
+        size_t per = (chunk + 256 * 16 - 1) / (256 * 16);
+        int bx = (int)(per > 256 ? 256 : (per < 1 ? 1 : per));
+        hipLaunchKernelGGL(joint_hist_kernel, dim3(bx, (unsigned)nchunks), dim3(256), 0, ctx->stream, a, b, n, chunk, hist);
+        hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, hist, n, chunk, scores);
+        MA_HIP(hipGetLastError());
+    }
+    MA_HIP(hipMemcpyAsync(ctx->pinned, scores, nchunks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < nchunks; i++) scores_host[i] = ((double*)ctx->pinned)[i];
+    *n_scores = (int)nchunks;
+    return MA_OK;
+}
+
+} // extern "C"

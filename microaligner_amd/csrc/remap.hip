@@ -1,0 +1,268 @@
+// Backward bilinear remap (cv2.remap INTER_LINEAR, BORDER_CONSTANT 0) and the tiled callers:
+//   Warper.warp()                       microaligner/optflow_reg/warper.py:37-76
+//   merge_two_flows / _merge_flow_in_tiles   optflow_reg/optflow_registrator.py:37-47,217-233
+// Semantics: SURVEY.md Appendix A.2 -- coordinates quantised to 1/32 px with round-half-even,
+// u8 uses the 15-bit fixed-point table, u16/f32 use float weights summed left to right.
+// HBM-bound gathers: one destination pixel per thread, rows coalesced along x.
+#include "ma_internal.h"
+
+namespace {
+
+struct Tap {
+    int sx, sy;   // integer source coordinate of the top-left tap
+    int fx, fy;   // 5-bit fractions
+};
+
+__device__ __forceinline__ short d_sat_short(int v) { return (short)(v < -32768 ? -32768 : (v > 32767 ? 32767 : v)); }
+
+__device__ __forceinline__ Tap quantise(float mx, float my)
+{
+    int sxq = d_cvround(mx * 32.f), syq = d_cvround(my * 32.f);
+    Tap t;
+    t.fx = sxq & 31; t.fy = syq & 31;
+    t.sx = d_sat_short(sxq >> 5); t.sy = d_sat_short(syq >> 5);
+    return t;
+}
+
+// 15-bit fixed-point bilinear weights of OpenCV's BilinearTab_i (A.2), including the
+// [32767,0,0,1] entry that the table's sum fix-up produces at zero fraction.
+__device__ __forceinline__ void weights_i(int fx, int fy, int w[4])
+{
+    if ((fx | fy) == 0) { w[0] = 32767; w[1] = 0; w[2] = 0; w[3] = 1; return; }
+    w[0] = (32 - fy) * (32 - fx) * 32; w[1] = (32 - fy) * fx * 32;
+    w[2] = fy * (32 - fx) * 32;        w[3] = fy * fx * 32;
+}
+__device__ __forceinline__ void weights_f(int fx, int fy, float w[4])
+{
+    // products of the exact 1-D weights (1 - f/32, f/32): exact in float
+    const float s = 1.f / 32.f;
+    float x1 = fx * s, x0 = 1.f - x1, y1 = fy * s, y0 = 1.f - y1;
+    w[0] = y0 * x0; w[1] = y0 * x1; w[2] = y1 * x0; w[3] = y1 * x1;
+}
+
+template <typename T> struct Interp;
+template <> struct Interp<uint8_t> {
+    __device__ static uint8_t run(uint8_t v0, uint8_t v1, uint8_t v2, uint8_t v3, int fx, int fy)
+    {
+        int w[4];
+        weights_i(fx, fy, w);
+        int acc = v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+        return (uint8_t)d_clamp((acc + (1 << 14)) >> 15, 0, 255);
+    }
+};
+template <> struct Interp<uint16_t> {
+    __device__ static uint16_t run(uint16_t v0, uint16_t v1, uint16_t v2, uint16_t v3, int fx, int fy)
+    {
+        float w[4];
+        weights_f(fx, fy, w);
+        float acc = (float)v0 * w[0] + (float)v1 * w[1] + (float)v2 * w[2] + (float)v3 * w[3];
+        return (uint16_t)d_clamp(d_cvround(acc), 0, 65535);
+    }
+};
+template <> struct Interp<float> {
+    __device__ static float run(float v0, float v1, float v2, float v3, int fx, int fy)
+    {
+        float w[4];
+        weights_f(fx, fy, w);
+        return v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3];
+    }
+};
+
+// ---- generic cv2.remap ------------------------------------------------------------------------
+template <typename T, int CN>
+__global__ __launch_bounds__(256) void remap_kernel(const T* __restrict__ src, int sh, int sw,
+                                                    const float2* __restrict__ map, int dh, int dw,
+                                                    T* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    float2 m = map[(size_t)y * dw + x];
+    Tap t = quantise(m.x, m.y);
+    T out[CN];
+    if (t.sx >= sw || t.sx + 1 < 0 || t.sy >= sh || t.sy + 1 < 0) {
+#pragma unroll
+        for (int k = 0; k < CN; k++) out[k] = 0;
+    } else {
+        const bool x0 = t.sx >= 0, x1 = t.sx + 1 < sw, y0 = t.sy >= 0, y1 = t.sy + 1 < sh;
+#pragma unroll
+        for (int k = 0; k < CN; k++) {
+            T v0 = (x0 && y0) ? src[((size_t)t.sy * sw + t.sx) * CN + k] : (T)0;
+            T v1 = (x1 && y0) ? src[((size_t)t.sy * sw + t.sx + 1) * CN + k] : (T)0;
+            T v2 = (x0 && y1) ? src[((size_t)(t.sy + 1) * sw + t.sx) * CN + k] : (T)0;
+            T v3 = (x1 && y1) ? src[((size_t)(t.sy + 1) * sw + t.sx + 1) * CN + k] : (T)0;
+            out[k] = Interp<T>::run(v0, v1, v2, v3, t.fx, t.fy);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < CN; k++) dst[((size_t)y * dw + x) * CN + k] = out[k];
+}
+
+// ---- Warper.warp(): window-local map = float(x_local) - flow, window-local constant border ----
+// A tap contributes iff it lies inside the window [0,P) AND inside the image (the window is the
+// zero-padded crop slicer.py builds); both cases read as 0, exactly what cv2.remap sees.
+template <typename T>
+__global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ img, MaTiling g,
+                                                         const float2* __restrict__ flow, T* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    int oy = 0, ox = 0;
+    if (g.T > 0) { oy = (y / g.T) * g.T - g.ov; ox = (x / g.T) * g.T - g.ov; }
+    const int lx = x - ox, ly = y - oy;
+    float2 f = flow[(size_t)y * g.W + x];
+    // warper.py:57-59: float32(float64(-flow) + arange) == the correctly rounded lx - flow
+    Tap t = quantise((float)lx - f.x, (float)ly - f.y);
+    T res = 0;
+    if (!(t.sx >= g.Pw || t.sx + 1 < 0 || t.sy >= g.Ph || t.sy + 1 < 0)) {
+        T v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int sx = t.sx + (k & 1), sy = t.sy + (k >> 1);
+            int ix = ox + sx, iy = oy + sy;
+            bool ok = sx >= 0 && sx < g.Pw && sy >= 0 && sy < g.Ph && (unsigned)ix < (unsigned)g.W &&
+                      (unsigned)iy < (unsigned)g.H;
+            v[k] = ok ? img[(size_t)iy * g.W + ix] : (T)0;
+        }
+        res = Interp<T>::run(v[0], v[1], v[2], v[3], t.fx, t.fy);
+    }
+    out[(size_t)y * g.W + x] = res;
+}
+
+// ---- flow merge ---------------------------------------------------------------------------------
+// per window: max over the zero-padded window of both flow components (numpy .max(), NaNs ignored)
+__global__ __launch_bounds__(256) void window_max_kernel(const float2* __restrict__ f1, const float2* __restrict__ f2,
+                                                         MaTiling g, float* __restrict__ maxes)
+{
+    const int widx = blockIdx.x;
+    int oy = 0, ox = 0;
+    if (g.T > 0) { int ty = widx / g.ntx, tx = widx - ty * g.ntx; oy = ty * g.T - g.ov; ox = tx * g.T - g.ov; }
+    const int ya = max(oy, 0), yb = min(oy + g.Ph, g.H), xa = max(ox, 0), xb = min(ox + g.Pw, g.W);
+    const bool padded = oy < 0 || ox < 0 || oy + g.Ph > g.H || ox + g.Pw > g.W;
+    const float init = padded ? 0.f : -INFINITY;
+    float m1 = init, m2 = init;
+    const int ww = xb - xa, n = (yb - ya) * ww;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        int yy = ya + i / ww, xx = xa + i % ww;
+        float2 a = f1[(size_t)yy * g.W + xx], b = f2[(size_t)yy * g.W + xx];
+        m1 = fmaxf(m1, fmaxf(a.x, a.y));
+        m2 = fmaxf(m2, fmaxf(b.x, b.y));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        m1 = fmaxf(m1, __shfl_down(m1, off));
+        m2 = fmaxf(m2, __shfl_down(m2, off));
+    }
+    __shared__ float s1[4], s2[4];
+    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = m1; s2[threadIdx.x >> 6] = m2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        maxes[widx * 2] = fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3]));
+        maxes[widx * 2 + 1] = fmaxf(fmaxf(s2[0], s2[1]), fmaxf(s2[2], s2[3]));
+    }
+}
+
+__global__ __launch_bounds__(256) void merge_flows_kernel(const float2* __restrict__ f1, const float2* __restrict__ f2,
+                                                          MaTiling g, const float* __restrict__ maxes,
+                                                          float2* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.W) return;
+    int oy = 0, ox = 0, widx = 0;
+    if (g.T > 0) {
+        int ty = y / g.T, tx = x / g.T;
+        widx = ty * g.ntx + tx;
+        oy = ty * g.T - g.ov; ox = tx * g.T - g.ov;
+    }
+    const size_t p = (size_t)y * g.W + x;
+    const float2 a = f1[p];
+    float2 res;
+    if (maxes[widx * 2] == 0.f) res = f2[p];               // flow1.max() == 0 -> flow2
+    else if (maxes[widx * 2 + 1] == 0.f) res = a;          // flow2.max() == 0 -> flow1
+    else {
+        // flow1 + cv.remap(flow2, -flow1): the map is -flow1 itself (absolute window coordinates, quirk Q1)
+        Tap t = quantise(-a.x, -a.y);
+        float2 s = make_float2(0.f, 0.f);
+        if (!(t.sx >= g.Pw || t.sx + 1 < 0 || t.sy >= g.Ph || t.sy + 1 < 0)) {
+            float2 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                int sx = t.sx + (k & 1), sy = t.sy + (k >> 1);
+                int ix = ox + sx, iy = oy + sy;
+                bool ok = sx >= 0 && sx < g.Pw && sy >= 0 && sy < g.Ph && (unsigned)ix < (unsigned)g.W &&
+                          (unsigned)iy < (unsigned)g.H;
+                v[k] = ok ? f2[(size_t)iy * g.W + ix] : make_float2(0.f, 0.f);
+            }
+            s.x = Interp<float>::run(v[0].x, v[1].x, v[2].x, v[3].x, t.fx, t.fy);
+            s.y = Interp<float>::run(v[0].y, v[1].y, v[2].y, v[3].y, t.fx, t.fy);
+        }
+        res = make_float2(a.x + s.x, a.y + s.y);
+    }
+    out[p] = res;
+}
+
+} // namespace
+
+extern "C" {
+
+int ma_remap_bilinear(ma_ctx* ctx, const void* src, int dtype, int cn, int sh, int sw, const float* map_xy, int dh,
+                      int dw, void* dst)
+{
+    MA_REQUIRE(ctx && src && map_xy && dst, "NULL argument");
+    MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
+    MA_REQUIRE(cn == 1 || cn == 2, "cn must be 1 or 2");
+    MA_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0, "empty image");
+    MA_REQUIRE(sh < 32767 && sw < 32767 && dh < 32767 && dw < 32767, "cv2.remap requires all dimensions < 32767");
+    MA_HIP(hipSetDevice(ctx->device));
+    MaProfScope ps(ctx, MA_K_WARP, (double)dh * dw);
+    dim3 grid((dw + 255) / 256, dh), block(256);
+    const float2* map = (const float2*)map_xy;
+#define LAUNCH(T, CN) hipLaunchKernelGGL((remap_kernel<T, CN>), grid, block, 0, ctx->stream, (const T*)src, sh, sw, map, dh, dw, (T*)dst)
+    if (dtype == MA_U8) { if (cn == 1) LAUNCH(uint8_t, 1); else LAUNCH(uint8_t, 2); }
+    else if (dtype == MA_U16) { if (cn == 1) LAUNCH(uint16_t, 1); else LAUNCH(uint16_t, 2); }
+    else { if (cn == 1) LAUNCH(float, 1); else LAUNCH(float, 2); }
+#undef LAUNCH
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile, int overlap,
+                  void* out)
+{
+    MA_REQUIRE(ctx && img && flow && out, "NULL argument");
+    MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
+    MA_REQUIRE(H > 0 && W > 0 && H <= 65535, "bad image size");
+    MA_REQUIRE(tile >= 0 && overlap >= 0, "tile/overlap must be >= 0");
+    MaTiling g = ma_make_tiling(H, W, tile, overlap);
+    MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
+    MA_HIP(hipSetDevice(ctx->device));
+    MaProfScope ps(ctx, MA_K_WARP, (double)H * W);
+    dim3 grid((W + 255) / 256, H), block(256);
+    const float2* f = (const float2*)flow;
+    if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)img, g, f, (uint8_t*)out);
+    else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)img, g, f, (uint16_t*)out);
+    else hipLaunchKernelGGL((warp_tiled_kernel<float>), grid, block, 0, ctx->stream, (const float*)img, g, f, (float*)out);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+int ma_merge_flows_tiled(ma_ctx* ctx, const float* flow1, const float* flow2, int H, int W, int tile, int overlap,
+                         float* out)
+{
+    MA_REQUIRE(ctx && flow1 && flow2 && out, "NULL argument");
+    MA_REQUIRE(H > 0 && W > 0 && H <= 65535, "bad image size");
+    MA_REQUIRE(tile >= 0 && overlap >= 0, "tile/overlap must be >= 0");
+    MaTiling g = ma_make_tiling(H, W, tile, overlap);
+    MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
+    MA_HIP(hipSetDevice(ctx->device));
+    const int nwin = g.ntx * g.nty;
+    MA_TRY(ma_dconst_reserve(ctx, (size_t)nwin * 2 * sizeof(float)));
+    float* maxes = (float*)ctx->dconst;
+    MaProfScope ps(ctx, MA_K_MERGE, (double)H * W);
+    hipLaunchKernelGGL(window_max_kernel, dim3(nwin), dim3(256), 0, ctx->stream, (const float2*)flow1,
+                       (const float2*)flow2, g, maxes);
+    hipLaunchKernelGGL(merge_flows_kernel, dim3((W + 255) / 256, H), dim3(256), 0, ctx->stream, (const float2*)flow1,
+                       (const float2*)flow2, g, maxes, (float2*)out);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+} // extern "C"

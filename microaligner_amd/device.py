@@ -1,0 +1,308 @@
+"""Device context, HBM-resident arrays and the primitive operations of the hot path.
+
+Thin Python over the C-ABI (include/microaligner_hip.h).  One `Context` per HIP
+device per process; `DeviceArray` is a dense row-major array in HBM.  All work is
+stream ordered on the context's stream, so intermediate results never visit the host.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+
+_DT = {np.dtype(np.uint8): L.MA_U8, np.dtype(np.uint16): L.MA_U16, np.dtype(np.float32): L.MA_F32}
+
+
+def _dt(dtype):
+    dtype = np.dtype(dtype)
+    if dtype not in _DT:
+        raise ValueError(f"unsupported image dtype {dtype}: the HIP path handles uint8, uint16 and float32")
+    return _DT[dtype]
+
+
+class DeviceArray:
+    """Dense row-major array living in HBM.  Freed back to the context's pool on `free()`/GC."""
+
+    __slots__ = ("ctx", "shape", "dtype", "ptr", "_nbytes_alloc", "_owner")
+
+    def __init__(self, ctx, shape, dtype, ptr, nbytes_alloc, owner=True):
+        self.ctx, self.shape, self.dtype, self.ptr = ctx, tuple(int(s) for s in shape), np.dtype(dtype), ptr
+        self._nbytes_alloc, self._owner = nbytes_alloc, owner
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def __len__(self):
+        return self.shape[0] if self.shape else 0
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        if out.nbytes:
+            L.check(self.ctx.lib.ma_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def copy(self):
+        out = self.ctx.empty(self.shape, self.dtype)
+        L.check(self.ctx.lib.ma_memcpy_d2d(self.ctx.handle, out.ptr, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr and self._owner and self.ctx is not None:
+            self.ctx._release(self.ptr, self._nbytes_alloc)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per HIP device.  Owns the C-side ma_ctx and a size-bucketed pool of HBM buffers."""
+
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        L.check(self.lib.ma_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        self._pool = {}
+        self._closed = False
+        lim = os.environ.get("MICROALIGNER_WORKSPACE_GB")
+        if lim:
+            L.check(self.lib.ma_ctx_set_workspace_limit(self.handle, int(float(lim) * (1 << 30))))
+
+    # -- memory --------------------------------------------------------------------------
+    def empty(self, shape, dtype):
+        shape = tuple(int(s) for s in shape)
+        dtype = np.dtype(dtype)
+        nbytes = max(int(np.prod(shape, dtype=np.int64)) * dtype.itemsize, 1)
+        bucket = (nbytes + 0xFFFF) & ~0xFFFF
+        free = self._pool.get(bucket)
+        if free:
+            ptr = free.pop()
+        else:
+            p = C.c_void_p()
+            rc = self.lib.ma_malloc(self.handle, bucket, C.byref(p))
+            if rc == L.MA_ENOMEM:
+                self.trim()
+                rc = self.lib.ma_malloc(self.handle, bucket, C.byref(p))
+            L.check(rc)
+            ptr = p.value
+        return DeviceArray(self, shape, dtype, ptr, bucket)
+
+    def zeros(self, shape, dtype):
+        a = self.empty(shape, dtype)
+        L.check(self.lib.ma_memset(self.handle, a.ptr, 0, a.nbytes))
+        return a
+
+    def asdevice(self, arr):
+        """numpy -> DeviceArray (H2D copy); DeviceArray passes through."""
+        if isinstance(arr, DeviceArray):
+            return arr
+        arr = np.ascontiguousarray(arr)
+        _dt(arr.dtype)
+        d = self.empty(arr.shape, arr.dtype)
+        if arr.nbytes:
+            L.check(self.lib.ma_memcpy_h2d(self.handle, d.ptr, arr.ctypes.data, arr.nbytes))
+        return d
+
+    def _release(self, ptr, bucket):
+        if self._closed:
+            return
+        self._pool.setdefault(bucket, []).append(ptr)
+
+    def trim(self):
+        """Return every pooled buffer to the driver."""
+        for free in self._pool.values():
+            for p in free:
+                self.lib.ma_free(self.handle, p)
+        self._pool = {}
+
+    def sync(self):
+        L.check(self.lib.ma_sync(self.handle))
+
+    def close(self):
+        if not self._closed:
+            self.trim()
+            self._closed = True
+            self.lib.ma_ctx_destroy(self.handle)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- events / profiling --------------------------------------------------------------------
+    def event(self):
+        e = C.c_void_p()
+        L.check(self.lib.ma_event_create(self.handle, C.byref(e)))
+        return e
+
+    def record(self, ev):
+        L.check(self.lib.ma_event_record(self.handle, ev))
+
+    def elapsed_ms(self, a, b):
+        ms = C.c_float()
+        L.check(self.lib.ma_event_elapsed_ms(self.handle, a, b, C.byref(ms)))
+        return ms.value
+
+    def profile(self, on=True):
+        L.check(self.lib.ma_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self):
+        L.check(self.lib.ma_profile_reset(self.handle))
+
+    def profile_get(self):
+        out = {}
+        for name, kid in L.KERNEL_IDS.items():
+            ms, n, px = C.c_double(), C.c_longlong(), C.c_double()
+            L.check(self.lib.ma_profile_get(self.handle, kid, C.byref(ms), C.byref(n), C.byref(px)))
+            out[name] = {"ms": ms.value, "launches": n.value, "px": px.value}
+        return out
+
+    # -- primitives (device in, device out) ---------------------------------------------------
+    def farneback(self, prev, nxt, winsize, iterations, tile=0, overlap=0, poly_n=1, poly_sigma=1.7, fused=False):
+        """cv2.calcOpticalFlowFarneback(prev, next, levels=0, GAUSSIAN) on the whole image (tile=0)
+        or on TileFlowCalc's overlapping windows, stitched (flow_calc.py:59-98)."""
+        if prev.shape != nxt.shape or prev.dtype != nxt.dtype or prev.ndim != 2:
+            raise ValueError("prev/next must be 2-D arrays of the same shape and dtype")
+        H, W = prev.shape
+        flow = self.empty((H, W, 2), np.float32)
+        L.check(self.lib.ma_farneback_tiled(self.handle, prev.ptr, nxt.ptr, _dt(prev.dtype), H, W, int(tile),
+                                            int(overlap), int(winsize), int(iterations), int(poly_n),
+                                            float(poly_sigma), L.MA_FB_MULADD_FUSED if fused else 0, flow.ptr))
+        return flow
+
+    def farneback_debug(self, prev, nxt, winsize, iterations, poly_sigma=1.7, fused=False):
+        H, W = prev.shape
+        flow = self.empty((H, W, 2), np.float32)
+        r0, r1, m0 = (self.empty((5, H, W), np.float32) for _ in range(3))
+        L.check(self.lib.ma_farneback_debug(self.handle, prev.ptr, nxt.ptr, _dt(prev.dtype), H, W, int(winsize),
+                                            int(iterations), float(poly_sigma),
+                                            L.MA_FB_MULADD_FUSED if fused else 0, flow.ptr, r0.ptr, r1.ptr, m0.ptr))
+        return flow, r0, r1, m0
+
+    def remap(self, src, map_xy):
+        """cv2.remap(src, map_xy, None, INTER_LINEAR)."""
+        cn = 1 if src.ndim == 2 else src.shape[2]
+        sh, sw = src.shape[:2]
+        dh, dw = map_xy.shape[:2]
+        if map_xy.dtype != np.float32 or map_xy.ndim != 3 or map_xy.shape[2] != 2:
+            raise ValueError("map must be (h, w, 2) float32")
+        dst = self.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), src.dtype)
+        L.check(self.lib.ma_remap_bilinear(self.handle, src.ptr, _dt(src.dtype), cn, sh, sw, map_xy.ptr, dh, dw,
+                                           dst.ptr))
+        return dst
+
+    def warp(self, img, flow, tile, overlap):
+        """Warper.warp() (warper.py:37-53)."""
+        H, W = img.shape
+        if flow.shape != (H, W, 2) or flow.dtype != np.float32:
+            raise ValueError(f"flow must be float32 of shape {(H, W, 2)}, got {flow.dtype} {flow.shape}")
+        out = self.empty((H, W), img.dtype)
+        L.check(self.lib.ma_warp_tiled(self.handle, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile),
+                                       int(overlap), out.ptr))
+        return out
+
+    def merge_flows(self, flow1, flow2, tile, overlap):
+        """_merge_flow_in_tiles (optflow_registrator.py:217-233)."""
+        if flow1.shape != flow2.shape:
+            raise ValueError("flows must have the same shape")
+        H, W = flow1.shape[:2]
+        out = self.empty((H, W, 2), np.float32)
+        L.check(self.lib.ma_merge_flows_tiled(self.handle, flow1.ptr, flow2.ptr, H, W, int(tile), int(overlap),
+                                              out.ptr))
+        return out
+
+    def pyr_down(self, img):
+        h, w = img.shape
+        out = self.empty(((h + 1) // 2, (w + 1) // 2), img.dtype)
+        L.check(self.lib.ma_pyr_down(self.handle, img.ptr, _dt(img.dtype), h, w, out.ptr))
+        return out
+
+    def pyr_up_flow(self, flow, dst_hw, scale=1.0):
+        """cv2.pyrUp(flow * scale, dstsize=(W, H)) with dst_hw = (H, W)."""
+        h, w = flow.shape[:2]
+        dh, dw = dst_hw
+        out = self.empty((dh, dw, 2), np.float32)
+        L.check(self.lib.ma_pyr_up_flow(self.handle, flow.ptr, h, w, float(scale), out.ptr, int(dh), int(dw)))
+        return out
+
+    def minmax(self, arr):
+        mn, mx = C.c_double(), C.c_double()
+        L.check(self.lib.ma_minmax(self.handle, arr.ptr, _dt(arr.dtype), arr.size, C.byref(mn), C.byref(mx)))
+        return mn.value, mx.value
+
+    def dog_u8(self, img, low_sigma=5, high_sigma=9):
+        h, w = img.shape
+        out = self.empty((h, w), np.uint8)
+        L.check(self.lib.ma_dog_u8(self.handle, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma),
+                                   out.ptr))
+        return out
+
+    def nmi_scores(self, a, b, chunk=0):
+        if a.dtype != np.uint8 or b.dtype != np.uint8 or a.size != b.size:
+            raise ValueError("NMI inputs must be uint8 arrays of equal size")
+        n = a.size
+        nch = 1 if (chunk <= 0 or chunk >= n) else (n + chunk - 1) // chunk
+        scores = (C.c_double * nch)()
+        got = C.c_int()
+        L.check(self.lib.ma_nmi_u8(self.handle, a.ptr, b.ptr, n, int(max(chunk, 0)), scores, nch, C.byref(got)))
+        return np.frombuffer(scores, dtype=np.float64, count=got.value).copy()
+
+    def max_project(self, stack):
+        nz = stack.shape[0]
+        out = self.empty(stack.shape[1:], stack.dtype)
+        L.check(self.lib.ma_max_project(self.handle, stack.ptr, _dt(stack.dtype), nz, out.size, out.ptr))
+        return out
+
+    def normalize_minmax_u8(self, arr):
+        out = self.empty(arr.shape, np.uint8)
+        L.check(self.lib.ma_normalize_minmax_u8(self.handle, arr.ptr, _dt(arr.dtype), arr.size, out.ptr))
+        return out
+
+
+_contexts = {}
+
+
+def default_device():
+    """Device index for this process: MICROALIGNER_DEVICE, else LOCAL_RANK (one process per GPU), else 0."""
+    for var in ("MICROALIGNER_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v is not None and v != "":
+            return int(v)
+    return 0
+
+
+def get_context(device=None):
+    """Process-wide context of a device (created on first use).  Raises when no HIP device exists."""
+    if device is None:
+        device = default_device()
+    ctx = _contexts.get(device)
+    if ctx is None:
+        n = C.c_int()
+        lib = L.load()
+        lib.ma_device_count(C.byref(n))
+        if n.value > 0:
+            device = device % n.value
+        ctx = _contexts[device] = Context(device)
+    return ctx
+
+
+def device_count():
+    n = C.c_int()
+    L.load().ma_device_count(C.byref(n))
+    return n.value

@@ -1,0 +1,68 @@
+"""Seeded synthetic image pairs: Gaussian-smoothed noise texture, reference =
+canvas crop, moving = canvas resampled at p + d(p) with d = global shift + smooth field, so that the
+true flow (mov(p) ~ ref(p + flow(p))) is d.  Used by the tests, the golden-vector script and bench.py.
+"""
+import numpy as np
+from scipy.ndimage import gaussian_filter
+
+GLOBAL_SHIFT = (3.3, -2.1)  # (dx, dy) in pixels
+
+
+def displacement(H, W, shift=GLOBAL_SHIFT, amp=2.0, dtype=np.float32):
+    """d(p) = shift + amp * (sin(2*pi*y/H*3), cos(2*pi*x/W*2)); returns (dx, dy) as (H,1)/(1,W)-broadcastable."""
+    y = np.arange(H, dtype=np.float64)[:, None]
+    x = np.arange(W, dtype=np.float64)[None, :]
+    dx = shift[0] + amp * np.sin(2 * np.pi * y / H * 3) + 0 * x
+    dy = shift[1] + amp * np.cos(2 * np.pi * x / W * 2) + 0 * y
+    return dx.astype(dtype), dy.astype(dtype)
+
+
+def _bilinear(canvas, ys, xs):
+    y0 = np.floor(ys).astype(np.int64)
+    x0 = np.floor(xs).astype(np.int64)
+    fy = (ys - y0).astype(np.float32)
+    fx = (xs - x0).astype(np.float32)
+    y0 = np.clip(y0, 0, canvas.shape[0] - 2)
+    x0 = np.clip(x0, 0, canvas.shape[1] - 2)
+    a = canvas[y0, x0]
+    b = canvas[y0, x0 + 1]
+    c = canvas[y0 + 1, x0]
+    d = canvas[y0 + 1, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def make_pair(H, W, seed=1, dtype=np.float32, shift=GLOBAL_SHIFT, amp=2.0, margin=20, sigma=4.0, band=2048):
+    """(ref, mov) of shape (H, W).  float32 in [0, 255]; uint8/uint16 are rounded casts (uint16 x 257)."""
+    rng = np.random.default_rng(seed)
+    canvas = rng.standard_normal((H + 2 * margin, W + 2 * margin), dtype=np.float32)
+    canvas = gaussian_filter(canvas, sigma, mode="reflect")
+    lo, hi = float(canvas.min()), float(canvas.max())
+    canvas = (canvas - lo) * (255.0 / (hi - lo))
+    ref = np.ascontiguousarray(canvas[margin:margin + H, margin:margin + W])
+    mov = np.empty((H, W), np.float32)
+    for y0 in range(0, H, band):  # banded to bound host memory on 16k x 16k
+        y1 = min(y0 + band, H)
+        yy = np.arange(y0, y1, dtype=np.float64)[:, None]
+        xx = np.arange(W, dtype=np.float64)[None, :]
+        dx = shift[0] + amp * np.sin(2 * np.pi * yy / H * 3)
+        dy = shift[1] + amp * np.cos(2 * np.pi * xx / W * 2)
+        mov[y0:y1] = _bilinear(canvas, yy + margin + dy, xx + margin + dx)
+    return _cast(ref, dtype), _cast(mov, dtype)
+
+
+def make_unrelated_pair(H, W, seed=1, dtype=np.float32):
+    """Two independent textures: registration cannot help, the gate must reject."""
+    a, _ = make_pair(H, W, seed, np.float32)
+    b, _ = make_pair(H, W, seed + 1000, np.float32)
+    return _cast(a, dtype), _cast(b, dtype)
+
+
+def _cast(img, dtype):
+    dtype = np.dtype(dtype)
+    if dtype == np.float32:
+        return np.ascontiguousarray(img, dtype=np.float32)
+    if dtype == np.uint8:
+        return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    if dtype == np.uint16:
+        return np.clip(np.rint(img * 257.0), 0, 65535).astype(np.uint16)
+    raise ValueError(f"unsupported dtype {dtype}")

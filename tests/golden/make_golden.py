@@ -1,0 +1,198 @@
+"""Generates tests/golden/*.json + *.npz by running the REFERENCE's own orchestration.
+
+Runs ONLY in the build container (needs /root/reference); nothing of the reference is copied:
+its classes are imported and driven, and their OpenCV / scikit-learn / dask dependencies -- absent
+from this image -- are replaced in sys.modules by stand-ins that forward to the C oracle
+(oracle/oracle.py).  What the fixtures pin: tile geometry, level / accept / reject logic, call
+order and the quirks Q1-Q3 of SURVEY.md 3d, given the primitives.  They do NOT pin the OpenCV
+arithmetic (parity unpinned, see oracle/ma_oracle.c).
+
+    python tests/golden/make_golden.py
+
+Each case stores: parameters + seed (inputs are regenerated from microaligner_amd.synthetic),
+the per-level MI scores / accept flags parsed from the reference's prints, SHA-256 of the returned
+flow and warped image, and a stride-5 sample of both for diagnostics.
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import re
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from microaligner_amd import synthetic  # noqa: E402
+
+CALLS = []
+
+
+def _install_standins():
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR, cv2.NORM_MINMAX, cv2.CV_32F, cv2.CV_8U = 1, 32, 5, 0
+    cv2.OPTFLOW_FARNEBACK_GAUSSIAN = 256
+    cv2.BORDER_CONSTANT, cv2.RANSAC, cv2.FAST_FEATURE_DETECTOR_TYPE_9_16 = 0, 8, 2
+    cv2.KeyPoint = type("KeyPoint", (), {})
+
+    def calcOpticalFlowFarneback(prev, next, flow, pyr_scale, levels, winsize, iterations, poly_n, poly_sigma,
+                                 flags):
+        assert flow is None and levels == 0 and flags == 256 and pyr_scale == 0.5
+        CALLS.append(("farneback", prev.shape, str(prev.dtype), winsize, iterations))
+        return O.calc_optical_flow_farneback(prev, next, winsize, iterations, poly_n, poly_sigma)
+
+    def remap(src, map1, map2, interpolation):
+        assert map2 is None and interpolation == 1
+        CALLS.append(("remap", src.shape, str(src.dtype)))
+        return O.remap(src, map1)
+
+    def pyrDown(img):
+        CALLS.append(("pyrDown", img.shape, str(img.dtype)))
+        return O.pyr_down(img)
+
+    def pyrUp(img, dstsize=None):
+        CALLS.append(("pyrUp", img.shape, tuple(dstsize) if dstsize is not None else None))
+        return O.pyr_up(img, dstsize)
+
+    def GaussianBlur(img, ksize, sigmaX, dst=None, sigmaY=0):
+        assert ksize[0] == ksize[1] and sigmaX == sigmaY
+        CALLS.append(("GaussianBlur", img.shape, ksize[0], sigmaX))
+        return O.gaussian_blur(img, ksize[0], sigmaX)
+
+    def normalize(src, dst, alpha, beta, norm_type, dtype):
+        assert dst is None and norm_type == 32
+        CALLS.append(("normalize", src.shape, str(src.dtype), dtype))
+        if dtype == 5:
+            return O.normalize_minmax_f32(src, alpha, beta)
+        assert (alpha, beta) == (0, 255)
+        return O.normalize_minmax_u8(src)
+
+    for f in (calcOpticalFlowFarneback, remap, pyrDown, pyrUp, GaussianBlur, normalize):
+        setattr(cv2, f.__name__, f)
+    sys.modules["cv2"] = cv2
+
+    dask = types.ModuleType("dask")
+
+    def delayed(fn):
+        return lambda *a, **k: (lambda: fn(*a, **k))
+
+    dask.delayed = delayed
+    dask.compute = lambda *thunks: tuple(t() for t in thunks)
+    dask.config = types.SimpleNamespace(set=lambda *a, **k: None)
+    sys.modules["dask"] = dask
+
+    sk = types.ModuleType("sklearn")
+    skm = types.ModuleType("sklearn.metrics")
+
+    def normalized_mutual_info_score(a, b):
+        assert a.dtype == np.uint8 and b.dtype == np.uint8
+        return O.nmi_u8(a, b)
+
+    skm.normalized_mutual_info_score = normalized_mutual_info_score
+    sk.metrics = skm
+    sys.modules["sklearn"] = sk
+    sys.modules["sklearn.metrics"] = skm
+
+    for name in ("skimage", "skimage.transform", "tifffile"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["skimage.transform"].AffineTransform = object
+    sys.modules["skimage.transform"].warp = None
+    sys.modules["skimage.transform"].EuclideanTransform = object
+
+
+CASES = {
+    # (i) defaults at a size with two pyramid levels, untiled Farneback, final pyrUp without x2 (Q2)
+    "defaults_420x404_f32": dict(shape=(420, 404), dtype="float32", seed=1, params=dict()),
+    # (ii) three levels incl. full resolution, DOG inputs, 9-window levels, merge path (Q1)
+    "fullres_dog_t100": dict(shape=(420, 404), dtype="float32", seed=2,
+                             params=dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True, tile_size=100, overlap=20)),
+    # (iii) non-multiple, non-square shape: right/bottom padding
+    "ragged_437x389_t150": dict(shape=(437, 389), dtype="float32", seed=3,
+                                params=dict(num_pyr_lvl=2, use_full_res_img=True, tile_size=150, overlap=16)),
+    # (iv) u8 inputs (the pipeline's dtype, utils.py:94)
+    "u8_410x420_t120": dict(shape=(410, 420), dtype="uint8", seed=4,
+                            params=dict(num_pyr_lvl=1, use_full_res_img=True, tile_size=120, overlap=12)),
+    # (v) forced reject: unrelated images -> zero-flow and pyrUp(m*4) branches (Q3)
+    "reject_420x420": dict(shape=(420, 420), dtype="float32", seed=5, unrelated=True,
+                           params=dict(num_pyr_lvl=2, use_full_res_img=True, tile_size=100, overlap=20)),
+    # (v-b) accept, then middle-level reject (pyrUp(m*4), Q3), then last-level reject (flow unchanged)
+    "reject_mid_s16": dict(shape=(420, 420), dtype="float32", seed=16, unrelated=True,
+                           params=dict(num_pyr_lvl=2, use_full_res_img=True, tile_size=100, overlap=20)),
+    # (v-c) accept, middle-level reject, last-level accept (merge after a x4 upscale)
+    "reject_mid_s38": dict(shape=(420, 420), dtype="float32", seed=38, unrelated=True,
+                           params=dict(num_pyr_lvl=2, use_full_res_img=True, tile_size=100, overlap=20)),
+    # (v-d) everything rejected without a full-resolution level: zeros, then pyrUp(m*2, full size)
+    "reject_nofull_s10": dict(shape=(420, 420), dtype="uint8", seed=10, unrelated=True,
+                              params=dict(num_pyr_lvl=2, use_full_res_img=False, tile_size=100, overlap=20)),
+    # (vi) single level
+    "single_level_300x260": dict(shape=(300, 260), dtype="float32", seed=6,
+                                 params=dict(num_pyr_lvl=0, use_full_res_img=True, tile_size=100, overlap=14)),
+    # (vii) not full-res with 2 levels and tiles: last-level upscale of the merged flow
+    "no_fullres_t100": dict(shape=(440, 408), dtype="uint8", seed=7,
+                            params=dict(num_pyr_lvl=2, use_full_res_img=False, tile_size=100, overlap=10)),
+}
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def make_inputs(case):
+    H, W = case["shape"]
+    if case.get("unrelated"):
+        return synthetic.make_unrelated_pair(H, W, case["seed"], case["dtype"])
+    return synthetic.make_pair(H, W, case["seed"], case["dtype"])
+
+
+def main():
+    _install_standins()
+    sys.path.insert(0, "/root/reference")
+    from microaligner import OptFlowRegistrator, Warper  # the reference's own classes
+
+    index = {}
+    for name, case in CASES.items():
+        ref, mov = make_inputs(case)
+        reg = OptFlowRegistrator()
+        for k, v in case["params"].items():
+            setattr(reg, k, v)
+        reg.ref_img, reg.mov_img = ref, mov
+        CALLS.clear()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            flow = reg.register()
+        log = buf.getvalue()
+        mi = [(float(a), float(b)) for a, b in re.findall(r"MI score after: (\S+) \| MI score before: (\S+)", log)]
+        factors = [int(f) for f in re.findall(r"Pyramid factor (\d+)", log)]
+        accepted = [("Better" in ln) for ln in log.splitlines() if "alignment than before" in ln]
+        reg_calls = [c[0] for c in CALLS]
+
+        w = Warper()
+        w.tile_size = case["params"].get("tile_size", 1000)
+        w.overlap = case["params"].get("overlap", 100)
+        w.image, w.flow = mov, flow.copy()
+        warped = w.warp()
+        # page warp of a u16 image with the same flow (the pipeline's dtype, __main__.py:296-301)
+        mov16 = synthetic._cast(synthetic.make_pair(*case["shape"], case["seed"], np.float32)[1], np.uint16)
+        w.image, w.flow = mov16, flow.copy()
+        warped16 = w.warp()
+
+        index[name] = dict(shape=list(case["shape"]), dtype=case["dtype"], seed=case["seed"],
+                           unrelated=bool(case.get("unrelated")), params=case["params"], factors=factors,
+                           mi=mi, accepted=accepted, flow_sha256=sha(flow), warped_sha256=sha(warped),
+                           warped_u16_sha256=sha(warped16), flow_dtype=str(flow.dtype), flow_shape=list(flow.shape),
+                           call_counts={k: reg_calls.count(k) for k in sorted(set(reg_calls))})
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), flow_s5=flow[::5, ::5], warped_s5=warped[::5, ::5],
+                            warped_u16_s5=warped16[::5, ::5])
+        print(name, "factors", factors, "accepted", accepted, "flow mean", flow.reshape(-1, 2).mean(0))
+    with open(os.path.join(HERE, "index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

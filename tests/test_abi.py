@@ -1,0 +1,74 @@
+"""The C-ABI shared library: it loads, exports every symbol include/microaligner_hip.h declares,
+and the product path fails loudly (no CPU fallback) when no HIP device is present."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "microaligner_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ma_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    from microaligner_amd import build, _lib
+    build.build()
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes prototypes out of sync with the header"
+    assert b"gfx950" in lib.ma_version()
+
+
+def test_code_object_targets_gfx950_only():
+    from microaligner_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_80"):
+        assert other not in blob
+
+
+def _have_gpu():
+    from microaligner_amd import device
+    try:
+        return device.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-device behaviour")
+def test_no_device_is_a_loud_error_not_a_fallback():
+    from microaligner_amd import OptFlowRegistrator, Warper, _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.ma_ctx_create(0, C.byref(h)) == _lib.MA_ENODEV
+    assert b"HIP device" in lib.ma_last_error()
+    reg = OptFlowRegistrator()
+    reg.ref_img = np.ones((200, 200), np.float32)
+    reg.mov_img = np.ones((200, 200), np.float32)
+    with pytest.raises(RuntimeError):
+        reg.register()
+    w = Warper()
+    w.image = np.ones((50, 50), np.uint8)
+    w.flow = np.zeros((50, 50, 2), np.float32)
+    with pytest.raises(RuntimeError):
+        w.warp()
+
+
+def test_null_arguments_are_rejected_without_a_device():
+    from microaligner_amd import _lib
+    lib = _lib.load()
+    assert lib.ma_sync(None) == _lib.MA_EINVAL
+    assert lib.ma_farneback_tiled(None, None, None, 2, 10, 10, 0, 0, 9, 1, 1, 1.7, 0, None) == _lib.MA_EINVAL
+    assert b"invalid argument" in lib.ma_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(_lib.MA_EINVAL)

@@ -1,0 +1,263 @@
+"""-m gpu: every HIP primitive against the CPU oracle on the same seeded inputs, through the C-ABI.
+Integer/byte outputs and -- because the kernels follow the oracle's operation order with FMA contraction
+off -- the float outputs too are required to be bit-identical (np.array_equal)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import register_oracle as RO
+from microaligner_amd import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(h, w, seed, dtype=np.float32, **kw):
+    return synthetic.make_pair(h, w, seed, dtype, **kw)
+
+
+# ---- Farneback ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,win,iters,dtype", [
+    ((131, 157), 19, 3, np.float32),
+    ((70, 64), 9, 1, np.float32),
+    ((200, 300), 51, 2, np.uint8),
+    ((257, 129), 99, 3, np.float32),
+    ((64, 200), 15, 3, np.uint16),
+    ((33, 31), 5, 2, np.float32),
+    ((300, 280), 99, 3, np.uint8),
+])
+def test_farneback_untiled_bit_exact(ctx, shape, win, iters, dtype):
+    ref, mov = pair(*shape, seed=shape[0] + win, dtype=dtype)
+    exp = O.calc_optical_flow_farneback(mov, ref, win, iters)
+    got = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), win, iters).numpy()
+    assert got.shape == exp.shape and got.dtype == np.float32
+    assert np.array_equal(got, exp), f"max abs diff {np.abs(got - exp).max()}"
+
+
+def test_farneback_intermediates_bit_exact(ctx):
+    ref, mov = pair(150, 170, 3)
+    flow, r0, r1, m0 = O.calc_optical_flow_farneback(mov, ref, 21, 1, dump=True)
+    gf, g0, g1, gm = [a.numpy() for a in ctx.farneback_debug(ctx.asdevice(mov), ctx.asdevice(ref), 21, 1)]
+    assert np.array_equal(g0, np.moveaxis(r0, 2, 0))
+    assert np.array_equal(g1, np.moveaxis(r1, 2, 0))
+    assert np.array_equal(gm, np.moveaxis(m0, 2, 0))
+    assert np.array_equal(gf, flow)
+
+
+def test_farneback_fused_mode_bit_exact_and_close(ctx):
+    ref, mov = pair(140, 150, 8)
+    exp = O.calc_optical_flow_farneback(mov, ref, 31, 3, fused=True)
+    got = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), 31, 3, fused=True).numpy()
+    assert np.array_equal(got, exp)
+    plain = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), 31, 3).numpy()
+    assert np.abs(got - plain).max() < 1e-3
+
+
+def test_farneback_huge_window_fallback(ctx):
+    ref, mov = pair(40, 700, 5)
+    exp = O.calc_optical_flow_farneback(mov, ref, 601, 2)
+    got = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), 601, 2).numpy()
+    assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("shape,tile,ov,dtype", [
+    ((420, 404), 100, 20, np.float32),
+    ((437, 389), 150, 16, np.uint8),
+    ((250, 610), 200, 21, np.float32),
+])
+def test_farneback_tiled_bit_exact(ctx, shape, tile, ov, dtype):
+    ref, mov = pair(*shape, seed=tile, dtype=dtype)
+    win = ov - (1 - ov % 2)
+    exp = RO.tile_flow(ref, mov, tile, ov, win, 3)
+    got = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), win, 3, tile=tile, overlap=ov).numpy()
+    assert np.array_equal(got, exp), f"max abs diff {np.abs(got - exp).max()}"
+
+
+def test_farneback_full_size_tile_bit_exact(ctx):
+    """One reference-sized window: 1200 x 1200, winsize 99, 3 iterations."""
+    ref, mov = pair(1200, 1200, 42)
+    exp = O.calc_optical_flow_farneback(mov, ref, 99, 3)
+    got = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), 99, 3).numpy()
+    assert np.array_equal(got, exp)
+    inner = got[300:-300, 300:-300].reshape(-1, 2)
+    assert np.abs(inner.mean(0) - np.array(synthetic.GLOBAL_SHIFT)).max() < 0.5
+
+
+def test_farneback_batches_when_workspace_is_small(ctx):
+    import ctypes as C
+    from microaligner_amd import _lib as L
+    ref, mov = pair(420, 404, 77)
+    exp = RO.tile_flow(ref, mov, 100, 20, 19, 2)
+    # one 140x140 window needs 140*192*4*20 B = 2.05 MiB of planes: 8 MiB forces batches of 3 windows
+    L.check(ctx.lib.ma_ctx_set_workspace_limit(ctx.handle, 8 << 20))
+    try:
+        got = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), 19, 2, tile=100, overlap=20).numpy()
+    finally:
+        L.check(ctx.lib.ma_ctx_set_workspace_limit(ctx.handle, 24 << 30))
+    assert np.array_equal(got, exp)
+
+
+def test_farneback_argument_errors(ctx):
+    ref, mov = pair(64, 64, 1)
+    d = ctx.asdevice(ref)
+    with pytest.raises(ValueError):
+        ctx.farneback(d, d, 9, 0)
+    with pytest.raises(ValueError):
+        ctx.farneback(d, d, 9, 1, poly_n=3)
+    with pytest.raises(ValueError):
+        ctx.farneback(d, ctx.asdevice(ref[:32]), 9, 1)
+
+
+# ---- remap / warp / merge --------------------------------------------------------------------------------
+def rand_flow(h, w, seed, scale):
+    rng = np.random.default_rng(seed)
+    from scipy.ndimage import gaussian_filter
+    f = np.stack([gaussian_filter(rng.standard_normal((h, w)), 6), gaussian_filter(rng.standard_normal((h, w)), 6)], -1)
+    return (f / np.abs(f).max() * scale).astype(np.float32)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("scale", [0.0, 2.5, 40.0])
+def test_warp_tiled_bit_exact(ctx, dtype, scale):
+    img, _ = pair(333, 290, 9, dtype)
+    flow = rand_flow(333, 290, 4, scale)
+    exp = RO.warp(img, flow, 100, 12)
+    got = ctx.warp(ctx.asdevice(img), ctx.asdevice(flow), 100, 12).numpy()
+    assert got.dtype == img.dtype and np.array_equal(got, exp)
+    if scale == 0.0:
+        assert np.array_equal(got, img)
+
+
+def test_warp_single_window_around_small_image(ctx):
+    img, _ = pair(200, 180, 2, np.uint16)
+    flow = rand_flow(200, 180, 5, 3.0)
+    assert np.array_equal(ctx.warp(ctx.asdevice(img), ctx.asdevice(flow), 1000, 100).numpy(), RO.warp(img, flow, 1000, 100))
+
+
+@pytest.mark.parametrize("dtype,cn", [(np.uint8, 1), (np.uint16, 1), (np.float32, 1), (np.float32, 2), (np.uint8, 2)])
+def test_remap_generic_bit_exact(ctx, dtype, cn):
+    rng = np.random.default_rng(3)
+    sh, sw, dh, dw = 61, 83, 70, 90
+    src = (rng.random((sh, sw) if cn == 1 else (sh, sw, cn)) * (65535 if dtype == np.uint16 else 255)).astype(dtype)
+    m = np.empty((dh, dw, 2), np.float32)
+    m[..., 0] = rng.uniform(-4, sw + 4, (dh, dw))
+    m[..., 1] = rng.uniform(-4, sh + 4, (dh, dw))
+    m[0, 0] = (1e12, -1e12)
+    m[0, 1] = (np.nan, 3.0)
+    m[0, 2] = (5.015625, 7.984375)  # exact 1/64 ties -> round-half-even buckets
+    exp = O.remap(src, m)
+    got = ctx.remap(ctx.asdevice(src), ctx.asdevice(m)).numpy()
+    assert np.array_equal(got, exp)
+
+
+def test_merge_flows_bit_exact_including_window_shortcuts(ctx):
+    h, w, T, ov = 330, 310, 100, 15
+    f1, f2 = rand_flow(h, w, 1, 3.0), rand_flow(h, w, 2, 2.0)
+    f1[:100, :100] = 0                       # window (0,0): flow1 all zero in its centre only
+    f1[100:200, 100:200] = -np.abs(f1[100:200, 100:200])
+    f2[200:, 200:] = 0
+    f1[0:130, 180:] = -1.0                   # padded window with only negative values -> max()==0 via padding
+    exp = RO.merge_flows(f1, f2, T, ov)
+    got = ctx.merge_flows(ctx.asdevice(f1), ctx.asdevice(f2), T, ov).numpy()
+    assert np.array_equal(got, exp)
+    z = np.zeros_like(f1)
+    assert np.array_equal(ctx.merge_flows(ctx.asdevice(z), ctx.asdevice(f2), T, ov).numpy(), f2)
+    assert np.array_equal(ctx.merge_flows(ctx.asdevice(f1), ctx.asdevice(z), T, ov).numpy(), RO.merge_flows(f1, z, T, ov))
+
+
+def test_merge_two_flows_function(ctx):
+    from microaligner_amd import merge_two_flows
+    f1, f2 = rand_flow(90, 80, 6, 2.0), rand_flow(90, 80, 7, 2.0)
+    assert np.array_equal(merge_two_flows(f1, f2), RO.merge_two_flows(f1, f2))
+
+
+# ---- pyramids -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(200, 300), (201, 303), (5, 7), (1, 9), (100, 1)])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_pyr_down_bit_exact(ctx, shape, dtype):
+    rng = np.random.default_rng(shape[0])
+    img = (rng.random(shape) * (65535 if dtype == np.uint16 else 255)).astype(dtype)
+    assert np.array_equal(ctx.pyr_down(ctx.asdevice(img)).numpy(), O.pyr_down(img))
+
+
+@pytest.mark.parametrize("src,dst", [((50, 70), (100, 140)), ((50, 70), (99, 139)), ((51, 33), (102, 65)),
+                                     ((2, 2), (4, 3)), ((105, 101), (210, 202))])
+@pytest.mark.parametrize("scale", [1.0, 2.0, 4.0])
+def test_pyr_up_flow_bit_exact(ctx, src, dst, scale):
+    f = rand_flow(src[0], src[1], 11, 5.0)
+    exp = O.pyr_up(f * np.float32(scale), dstsize=dst[::-1])
+    got = ctx.pyr_up_flow(ctx.asdevice(f), dst, scale).numpy()
+    assert np.array_equal(got, exp)
+
+
+def test_pyr_up_rejects_incompatible_size(ctx):
+    f = ctx.asdevice(rand_flow(10, 10, 1, 1.0))
+    with pytest.raises(ValueError):
+        ctx.pyr_up_flow(f, (25, 20), 1.0)
+
+
+# ---- DOG / min-max ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("shape", [(210, 260), (45, 300), (130, 37)])
+def test_dog_bit_exact(ctx, dtype, shape):
+    img, _ = pair(*shape, seed=shape[1], dtype=dtype)
+    exp = O.dog(img, True)
+    got = ctx.dog_u8(ctx.asdevice(img)).numpy()
+    assert got.dtype == np.uint8 and np.array_equal(got, exp)
+
+
+def test_dog_special_cases_and_minmax(ctx):
+    from microaligner_amd import OptFlowRegistrator
+    reg = OptFlowRegistrator()
+    z = np.zeros((40, 40), np.float32)
+    assert reg.dog(z, True) is z and reg.dog(z, False) is z
+    c = np.full((64, 64), 9, np.uint8)
+    assert np.all(reg.dog(c, True) == 0)
+    img, _ = pair(99, 77, 1)
+    assert ctx.minmax(ctx.asdevice(img)) == (float(img.min()), float(img.max()))
+    assert np.array_equal(reg.dog(img, True), O.dog(img, True))
+
+
+def test_max_project_and_normalize_u8(ctx):
+    rng = np.random.default_rng(0)
+    stack = rng.integers(0, 60000, (5, 120, 130)).astype(np.uint16)
+    mp = ctx.max_project(ctx.asdevice(stack))
+    assert np.array_equal(mp.numpy(), stack.max(0))
+    got = ctx.normalize_minmax_u8(mp).numpy()
+    exp = O.normalize_minmax_u8(stack.max(0).astype(np.float32))
+    assert np.array_equal(got, exp)
+
+
+# ---- NMI ------------------------------------------------------------------------------------------------------
+def test_nmi_matches_oracle_and_sklearn(ctx):
+    from sklearn.metrics import normalized_mutual_info_score as nmi
+    ref, mov = pair(300, 310, 12)
+    a, b = O.dog(ref, True), O.dog(mov, True)
+    got = ctx.nmi_scores(ctx.asdevice(a), ctx.asdevice(b), 0)
+    assert got.shape == (1,)
+    assert abs(got[0] - O.nmi_u8(a, b)) < 1e-12
+    assert abs(got[0] - nmi(a.ravel(), b.ravel())) < 1e-12
+    chunk = 100 * 100
+    got = ctx.nmi_scores(ctx.asdevice(a), ctx.asdevice(b), chunk)
+    fa, fb = a.ravel(), b.ravel()
+    exp = [O.nmi_u8(fa[i:i + chunk], fb[i:i + chunk]) for i in range(0, fa.size, chunk)]
+    np.testing.assert_allclose(got, exp, rtol=0, atol=1e-12)
+
+
+def test_nmi_special_cases(ctx):
+    z = np.zeros((50, 60), np.uint8)
+    r = np.random.default_rng(1).integers(0, 7, (50, 60)).astype(np.uint8)
+    dz, dr = ctx.asdevice(z), ctx.asdevice(r)
+    assert ctx.nmi_scores(dz, dz)[0] == 1.0
+    assert ctx.nmi_scores(dz, dr)[0] == 0.0
+    assert abs(ctx.nmi_scores(dr, dr)[0] - 1.0) < 1e-12
+
+
+def test_mi_tiled_host_function(ctx):
+    from microaligner_amd.shared_modules.similarity_scoring import mi_tiled, check_if_higher_similarity
+    ref, mov = pair(260, 250, 3)
+    a, b = O.dog(ref, True), O.dog(mov, True)
+    assert abs(mi_tiled(a, b, 100) - RO.mi_tiled(a, b, 100)) < 1e-12      # tiled: 7 chunks
+    assert abs(mi_tiled(a, b, 1000) - RO.mi_tiled(a, b, 1000)) < 1e-12    # whole image
+    assert check_if_higher_similarity(a, a, b, 100, verbose=False) == [True]
+    z = np.zeros((260, 250), np.float32)
+    assert mi_tiled(z, z, 1000) == 1.0
