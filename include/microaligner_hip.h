@@ -59,7 +59,7 @@ int ma_device_count(int* count);
 int ma_ctx_create(int device, ma_ctx** out);
 void ma_ctx_destroy(ma_ctx* ctx);
 int ma_sync(ma_ctx* ctx);
-/* Upper bound, in bytes, for the internal tile-batch workspace (default 24 GiB). */
+/* Upper bound, in bytes, for the internal tile-batch workspace (default 48 GiB). */
 int ma_ctx_set_workspace_limit(ma_ctx* ctx, size_t bytes);
 /* The ctx's hipStream_t as an opaque pointer (for event timing by the caller). */
 void* ma_ctx_stream(ma_ctx* ctx);

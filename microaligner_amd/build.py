@@ -20,6 +20,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wall", "-Wno-unused-function"]
 
 
+def _flags():
+    # MA_HIPCC_EXTRA: extra compiler flags for experiments (e.g. "-fno-slp-vectorize")
+    return FLAGS + os.environ.get("MA_HIPCC_EXTRA", "").split()
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.sep not in cand or os.path.exists(cand)):
@@ -45,7 +50,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + _flags() + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

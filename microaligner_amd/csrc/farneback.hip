@@ -232,21 +232,27 @@ __global__ __launch_bounds__(64 * NW) void fb_blur_v(FbGeom g, int m, const floa
 #pragma unroll
     for (int o = -1; o <= R - 2; o++) Q[(o + R) % R] = lds[(jb + o) * 64 + lane];
 
-    for (int i0 = 0; i0 < m; i0 += R) {
+    // full groups of R taps: branch-free, the windows rotate through statically indexed registers
+    const int full = m / R;
+    for (int g = 0; g < full; g++) {
 #pragma unroll
         for (int ii = 0; ii < R; ii++) {
-            const int i = i0 + ii + 1;
-            if (i <= m) {
-                const float ki = taps[i];
+            const int i = g * R + ii + 1;
+            const float ki = taps[i];
 #pragma unroll
-                for (int r = 0; r < R; r++)
-                    acc[r] = d_muladd<FUSED>(P[(r + ii + 1) % R] + Q[((r - ii - 1) % R + R) % R], ki, acc[r]);
-                if (i < m) {
-                    P[(ii + 1) % R] = lds[(jb + i + R) * 64 + lane];
-                    Q[((-ii - 2) % R + R) % R] = lds[(jb - i - 1) * 64 + lane];
-                }
-            }
+            for (int r = 0; r < R; r++)
+                acc[r] = d_muladd<FUSED>(P[(r + ii + 1) % R] + Q[((r - ii - 1) % R + R) % R], ki, acc[r]);
+            // next tap's entering rows (index clamped: the last tap of the last group reads nothing it needs)
+            P[(ii + 1) % R] = lds[min(jb + i + R, rows - 1) * 64 + lane];
+            Q[((-ii - 2) % R + R) % R] = lds[max(jb - i - 1, 0) * 64 + lane];
         }
+    }
+    // remaining m % R taps straight from LDS (same accumulation order)
+    for (int i = full * R + 1; i <= m; i++) {
+        const float ki = taps[i];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            acc[r] = d_muladd<FUSED>(lds[(jb + r + i) * 64 + lane] + lds[(jb + r - i) * 64 + lane], ki, acc[r]);
     }
     const int x = x0 + lane;
     if (x < Pw) {
@@ -302,21 +308,24 @@ __global__ __launch_bounds__(64 * NW) void fb_blur_h_solve(FbGeom g, int m, cons
         for (int o = 1; o <= R; o++) P[o % R] = row[cb + o];
 #pragma unroll
         for (int o = -1; o <= R - 2; o++) Q[(o + R) % R] = row[cb + o];
-        for (int i0 = 0; i0 < m; i0 += R) {
+        const int full = m / R;
+        for (int g = 0; g < full; g++) {
 #pragma unroll
             for (int ii = 0; ii < R; ii++) {
-                const int i = i0 + ii + 1;
-                if (i <= m) {
-                    const float ki = taps[i];
+                const int i = g * R + ii + 1;
+                const float ki = taps[i];
 #pragma unroll
-                    for (int r = 0; r < R; r++)
-                        acc[r] = d_muladd<FUSED>(Q[((r - ii - 1) % R + R) % R] + P[(r + ii + 1) % R], ki, acc[r]);
-                    if (i < m) {
-                        P[(ii + 1) % R] = row[cb + i + R];
-                        Q[((-ii - 2) % R + R) % R] = row[cb - i - 1];
-                    }
-                }
+                for (int r = 0; r < R; r++)
+                    acc[r] = d_muladd<FUSED>(Q[((r - ii - 1) % R + R) % R] + P[(r + ii + 1) % R], ki, acc[r]);
+                P[(ii + 1) % R] = row[min(cb + i + R, cols - 1)];
+                Q[((-ii - 2) % R + R) % R] = row[max(cb - i - 1, 0)];
             }
+        }
+        for (int i = full * R + 1; i <= m; i++) {
+            const float ki = taps[i];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                acc[r] = d_muladd<FUSED>(row[cb + r - i] + row[cb + r + i], ki, acc[r]);
         }
 #pragma unroll
         for (int r = 0; r < R; r++) hs[ch][r] = acc[r];

@@ -41,7 +41,7 @@ struct ma_ctx {
     // grow-only device workspace reused by every call (tile batches, DOG temporaries, histograms)
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    size_t ws_limit = (size_t)24 << 30;
+    size_t ws_limit = (size_t)48 << 30;
     // small pinned host buffer for scalar results (min/max, NMI scores)
     void* pinned = nullptr;
     size_t pinned_bytes = 0;

@@ -1,0 +1,101 @@
+"""Multi-GPU driver: independent units, one process per HIP device, no data-path collective.
+
+The hot path shards over independent units: (ref, mov) pairs -- cycles against a fixed
+reference, channels, mosaic tiles -- and the channel x z pages that reuse one flow.  Nothing is exchanged
+between units, so the partition is a static round-robin over ranks and the only communication is the optional
+gather of results onto rank 0 through the host (torch.distributed with the gloo backend; the GPUs never talk
+to each other, xGMI/RCCL are not involved).  Launch with
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 your_script.py
+
+each process picks its device from LOCAL_RANK (microaligner_amd.device.default_device).
+The reference's cycle CHAIN (ref_{k+1} = warp(mov_k), __main__.py:418-424) is serial across cycles and is not
+sharded here; its per-cycle page warps are (warp_pages).
+"""
+import os
+from typing import Callable, List, Optional, Sequence
+
+
+def world():
+    """(rank, world_size) from torch.distributed if initialised, else from the torchrun environment, else (0, 1)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def shard(n_units: int, rank: int, world_size: int) -> List[int]:
+    """Indices of the units rank `rank` owns: static round-robin, as dask would deal tasks to workers."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of size {world_size}")
+    return list(range(rank, n_units, world_size))
+
+
+def run_sharded(units: Sequence, fn: Callable, gather: bool = True, dst: int = 0):
+    """Apply `fn(unit)` to this rank's share of `units`.
+
+    gather=False: returns {unit_index: result} for the local share (results stay where they were computed).
+    gather=True : rank `dst` returns the full list in unit order, the other ranks return None; results travel
+                  as host objects (numpy arrays) over gloo.
+    """
+    rank, ws = world()
+    mine = shard(len(units), rank, ws)
+    local = {i: fn(units[i]) for i in mine}
+    if not gather:
+        return local
+    if ws == 1:
+        return [local[i] for i in range(len(units))]
+    import torch.distributed as dist
+    bucket: Optional[list] = [None] * ws if rank == dst else None
+    dist.gather_object(local, bucket, dst=dst)
+    if rank != dst:
+        return None
+    merged = {}
+    for part in bucket:
+        merged.update(part)
+    return [merged[i] for i in range(len(units))]
+
+
+def register_pairs(pairs: Sequence, params: Optional[dict] = None, warp: bool = False, gather: bool = True):
+    """Register every (ref, mov) pair of `pairs` on this rank's GPU share.
+    Returns flows (and warped moving images if warp=True) as numpy arrays, in pair order on rank 0."""
+    from . import OptFlowRegistrator, Warper
+    params = dict(params or {})
+
+    def one(pair):
+        ref, mov = pair
+        reg = OptFlowRegistrator()
+        reg.verbose = False
+        for k, v in params.items():
+            setattr(reg, k, v)
+        reg.ref_img, reg.mov_img = ref, mov
+        flow = reg.register()
+        if not warp:
+            return flow
+        w = Warper()
+        w.tile_size, w.overlap = reg.tile_size, reg.overlap
+        w.image, w.flow = mov, flow
+        return flow, w.warp()
+
+    return run_sharded(pairs, one, gather=gather)
+
+
+def warp_pages(pages: Sequence, flow, tile_size: int = 1000, overlap: int = 100, gather: bool = True):
+    """Apply ONE flow to many pages (channels x z-planes of a cycle, __main__.py:288-302,427-433), pages dealt
+    round-robin to the ranks; each rank uploads the flow once and keeps it in HBM for all of its pages."""
+    from . import Warper
+    from .device import get_context
+    state = {}
+
+    def one(page):
+        if "flow" not in state:
+            state["flow"] = get_context().asdevice(flow)
+        w = Warper()
+        w.tile_size, w.overlap = tile_size, overlap
+        w.image, w.flow = get_context().asdevice(page), state["flow"]
+        return w.warp().numpy()
+
+    return run_sharded(pages, one, gather=gather)

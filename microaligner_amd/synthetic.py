@@ -2,8 +2,11 @@
 canvas crop, moving = canvas resampled at p + d(p) with d = global shift + smooth field, so that the
 true flow (mov(p) ~ ref(p + flow(p))) is d.  Used by the tests, the golden-vector script and bench.py.
 """
+import os
+from concurrent.futures import ThreadPoolExecutor
+
 import numpy as np
-from scipy.ndimage import gaussian_filter
+from scipy.ndimage import gaussian_filter1d
 
 GLOBAL_SHIFT = (3.3, -2.1)  # (dx, dy) in pixels
 
@@ -31,22 +34,44 @@ def _bilinear(canvas, ys, xs):
     return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
 
 
-def make_pair(H, W, seed=1, dtype=np.float32, shift=GLOBAL_SHIFT, amp=2.0, margin=20, sigma=4.0, band=2048):
+def _smooth(canvas, sigma, band=512):
+    """scipy.ndimage.gaussian_filter(canvas, sigma, mode="reflect"), bit for bit, but with each 1-D pass cut into
+    independent column / row bands that run on a thread pool (scipy releases the GIL)."""
+    tmp, out = np.empty_like(canvas), np.empty_like(canvas)
+    H, W = canvas.shape
+
+    def cols(x0):
+        gaussian_filter1d(canvas[:, x0:x0 + band], sigma, axis=0, mode="reflect", output=tmp[:, x0:x0 + band])
+
+    def rows(y0):
+        gaussian_filter1d(tmp[y0:y0 + band], sigma, axis=1, mode="reflect", output=out[y0:y0 + band])
+
+    with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:
+        list(ex.map(cols, range(0, W, band)))
+        list(ex.map(rows, range(0, H, band)))
+    return out
+
+
+def make_pair(H, W, seed=1, dtype=np.float32, shift=GLOBAL_SHIFT, amp=2.0, margin=20, sigma=4.0, band=512):
     """(ref, mov) of shape (H, W).  float32 in [0, 255]; uint8/uint16 are rounded casts (uint16 x 257)."""
     rng = np.random.default_rng(seed)
     canvas = rng.standard_normal((H + 2 * margin, W + 2 * margin), dtype=np.float32)
-    canvas = gaussian_filter(canvas, sigma, mode="reflect")
+    canvas = _smooth(canvas, sigma)
     lo, hi = float(canvas.min()), float(canvas.max())
     canvas = (canvas - lo) * (255.0 / (hi - lo))
     ref = np.ascontiguousarray(canvas[margin:margin + H, margin:margin + W])
     mov = np.empty((H, W), np.float32)
-    for y0 in range(0, H, band):  # banded to bound host memory on 16k x 16k
+
+    def resample(y0):  # banded: bounds host memory on 16k x 16k and runs on the thread pool
         y1 = min(y0 + band, H)
         yy = np.arange(y0, y1, dtype=np.float64)[:, None]
         xx = np.arange(W, dtype=np.float64)[None, :]
         dx = shift[0] + amp * np.sin(2 * np.pi * yy / H * 3)
         dy = shift[1] + amp * np.cos(2 * np.pi * xx / W * 2)
         mov[y0:y1] = _bilinear(canvas, yy + margin + dy, xx + margin + dx)
+
+    with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
+        list(ex.map(resample, range(0, H, band)))
     return _cast(ref, dtype), _cast(mov, dtype)
 
 

@@ -92,7 +92,7 @@ def test_farneback_batches_when_workspace_is_small(ctx):
     try:
         got = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), 19, 2, tile=100, overlap=20).numpy()
     finally:
-        L.check(ctx.lib.ma_ctx_set_workspace_limit(ctx.handle, 24 << 30))
+        L.check(ctx.lib.ma_ctx_set_workspace_limit(ctx.handle, 48 << 30))
     assert np.array_equal(got, exp)
 
 

@@ -94,8 +94,10 @@ def test_recovers_the_synthetic_displacement():
     reg.ref_img, reg.mov_img = ref, mov
     flow = reg.register()
     assert all(r.accepted for r in reg.level_reports)
-    inner = flow[150:-150, 150:-150].reshape(-1, 2)
-    assert np.abs(inner.mean(0) - np.array(synthetic.GLOBAL_SHIFT)).max() < 0.3
+    dx, dy = synthetic.displacement(H, W)
+    true = np.stack([dx, dy], -1)[150:-150, 150:-150]
+    err = np.abs(flow[150:-150, 150:-150] - true)
+    assert err.mean() < 0.25 and np.percentile(err, 99) < 1.0
     w = Warper()
     w.tile_size, w.overlap = 400, 60
     w.image, w.flow = mov, flow
@@ -114,7 +116,9 @@ def test_full_size_properties_4096(ctx):
     # identical images: every window's flow is exactly zero except the L-shaped band of width iters*m+1
     flow = ctx.farneback(dref, dref, 99, 3, tile=1000, overlap=100).numpy()
     assert flow.shape == (H, W, 2)
-    assert np.all(flow[:3000, :3000] == 0)           # windows fully inside: centres are band-free
+    # the band (magnitude <~0.3 px at the very edge) leaks ~1e-7 px into the kept centres at overlap 100
+    assert np.abs(flow[:3000, :3000]).max() < 1e-5
+    assert np.all(flow[:800, :800] == 0)
     assert np.abs(flow).max() < 1.0
     # warp with a zero flow is an exact copy; with an integer flow an exact shifted copy inside each window
     z = ctx.zeros((H, W, 2), np.float32)
