@@ -148,9 +148,12 @@ int ma_pyr_up_flow(ma_ctx* ctx, const float* src, int h, int w, float scale, flo
 int ma_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn_host, double* mx_host);
 /* The body of OptFlowRegistrator.dog (optflow_registrator.py:259-274):
  * normalize(0,1,MINMAX,32F) -> GaussianBlur(k,k,low) & GaussianBlur(k,k,high)
- * with k = low_sigma*8+1 -> hs-ls -> normalize(0,255,MINMAX,8U). */
+ * with k = low_sigma*8+1 -> hs-ls -> normalize(0,255,MINMAX,8U).  The whole chain is stream ordered
+ * (its scalars never visit the host).  If src_max_is_zero_host is not NULL the call synchronises and
+ * reports whether src.max() == 0, the case in which the reference returns the image unchanged (:256-257);
+ * dst is all zero then. */
 int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma,
-              uint8_t* dst);
+              uint8_t* dst, int* src_max_is_zero_host);
 
 /* ---- NMI gate -----------------------------------------------------------------
  * mi_tiled (similarity_scoring.py:27-50): normalized_mutual_info_score of two

@@ -16,8 +16,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmicroaligner_hip.so")
 SOURCES = ["ma_api.hip", "farneback.hip", "remap.hip", "pyramid.hip", "dog.hip", "nmi.hip"]
 HEADERS = [os.path.join(CSRC, "ma_internal.h"), os.path.join(HERE, "..", "include", "microaligner_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function"]
+# -fno-slp-vectorize: the SLP vectoriser packs the sliding-window blur into v_pk_* ops with a storm of
+# register-pair shuffles (measured 1.65x slower on blur_h_solve, profiles/r01_*); packed math is written by hand
+# where it pays.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
 def _flags():

@@ -3,7 +3,9 @@
 //   -> hs - ls -> normalize(0,255,MINMAX,8U)
 // plus the min/max reductions it needs and the input conditioning of SURVEY 8f-2
 // (np.maximum fold over z, utils.py:92; cv2.normalize -> u8, utils.py:94).
-// Semantics: SURVEY.md Appendix A.5.  Both sigmas share every load; rows first, then columns.
+// Semantics: SURVEY.md Appendix A.5.  Rows first (plain left-to-right accumulation), then columns
+// (symmetric form); both sigmas share every load.  No host synchronisation inside the chain: the
+// normalisation scalars are derived on the device from the reduced min/max exactly as OpenCV derives them.
 #include "ma_internal.h"
 
 #include <cfloat>
@@ -12,6 +14,21 @@
 namespace {
 
 // ---- min / max ------------------------------------------------------------------------------
+__device__ __forceinline__ void block_minmax_256(float lo, float hi, float* out2)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_down(lo, off));
+        hi = fmaxf(hi, __shfl_down(hi, off));
+    }
+    __shared__ float slo[4], shi[4];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out2[0] = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
+        out2[1] = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void minmax_partial(const T* __restrict__ src, size_t n, float* __restrict__ part)
 {
@@ -20,53 +37,68 @@ __global__ __launch_bounds__(256) void minmax_partial(const T* __restrict__ src,
         float v = (float)src[i];
         lo = fminf(lo, v); hi = fmaxf(hi, v);
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        lo = fminf(lo, __shfl_down(lo, off));
-        hi = fmaxf(hi, __shfl_down(hi, off));
-    }
-    __shared__ float slo[4], shi[4];
-    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        part[blockIdx.x * 2] = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
-        part[blockIdx.x * 2 + 1] = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
-    }
+    block_minmax_256(lo, hi, part + blockIdx.x * 2);
 }
 
 __global__ __launch_bounds__(256) void minmax_final(const float* __restrict__ part, int nparts, float* __restrict__ out)
 {
     float lo = INFINITY, hi = -INFINITY;
     for (int i = threadIdx.x; i < nparts; i += 256) { lo = fminf(lo, part[i * 2]); hi = fmaxf(hi, part[i * 2 + 1]); }
-    for (int off = 32; off > 0; off >>= 1) {
-        lo = fminf(lo, __shfl_down(lo, off));
-        hi = fmaxf(hi, __shfl_down(hi, off));
-    }
-    __shared__ float slo[4], shi[4];
-    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        out[0] = fminf(fminf(slo[0], slo[1]), fminf(slo[2], slo[3]));
-        out[1] = fmaxf(fmaxf(shi[0], shi[1]), fmaxf(shi[2], shi[3]));
-    }
+    block_minmax_256(lo, hi, out);
 }
 
-constexpr int MM_BLOCKS = 1024;
+constexpr int MM_BLOCKS = 2048;
 
-// min/max of a device array -> host doubles (synchronises).  Uses ctx->dconst for the partials.
-int minmax_impl(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn, double* mx)
+// scalars of the DOG chain, produced and consumed on the device
+struct DogScalars {
+    float mm_src[2];   // min, max of the input
+    float mm_diff[2];  // min, max of hs - ls
+    float a, b;        // normalize(src, 0, 1, MINMAX, 32F):  v*a + b
+    float a8, b8;      // normalize(diff, 0, 255, MINMAX, 8U): v*a8 + b8
+    int src_max_is_zero;
+};
+
+// normalize(src, 0, 1, NORM_MINMAX, CV_32F): scale rounded to float, shift = (float)0 - (float)(smin*scale)
+__global__ void dog_params_in(DogScalars* s)
 {
-    MA_TRY(ma_dconst_reserve(ctx, (MM_BLOCKS * 2 + 2) * sizeof(float)));
-    MA_TRY(ma_pinned_reserve(ctx, 64));
-    float* part = (float*)ctx->dconst;
-    float* out = part + MM_BLOCKS * 2;
+    double smin = s->mm_src[0], smax = s->mm_src[1];
+    double scale = (1.0 - 0.0) * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
+    scale = (float)scale;
+    s->a = (float)scale;
+    s->b = (float)0.0 - (float)(smin * scale);
+    s->src_max_is_zero = smax == 0.0;
+}
+// normalize(diff, 0, 255, NORM_MINMAX, CV_8U): scale/shift in double, applied in float
+__global__ void dog_params_out(DogScalars* s)
+{
+    double dmin = s->mm_diff[0], dmax = s->mm_diff[1];
+    double scale = 255. * (dmax - dmin > DBL_EPSILON ? 1. / (dmax - dmin) : 0);
+    double shift = 0. - dmin * scale;
+    s->a8 = (float)scale;
+    s->b8 = (float)shift;
+}
+
+int launch_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, float* part, float* out2)
+{
     int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
     if (blocks > MM_BLOCKS) blocks = MM_BLOCKS;
     if (blocks < 1) blocks = 1;
     if (dtype == MA_U8) hipLaunchKernelGGL((minmax_partial<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)src, n, part);
     else if (dtype == MA_U16) hipLaunchKernelGGL((minmax_partial<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint16_t*)src, n, part);
     else hipLaunchKernelGGL((minmax_partial<float>), dim3(blocks), dim3(256), 0, ctx->stream, (const float*)src, n, part);
-    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, ctx->stream, part, blocks, out);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, ctx->stream, part, blocks, out2);
     MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+// min/max of a device array -> host doubles (synchronises).  Uses ctx->dconst for the partials.
+int minmax_host(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn, double* mx)
+{
+    MA_TRY(ma_dconst_reserve(ctx, (MM_BLOCKS * 2 + 64) * sizeof(float)));
+    MA_TRY(ma_pinned_reserve(ctx, 64));
+    float* part = (float*)ctx->dconst;
+    float* out = part + MM_BLOCKS * 2;
+    MA_TRY(launch_minmax(ctx, src, dtype, n, part, out));
     float* h = (float*)ctx->pinned;
     MA_HIP(hipMemcpyAsync(h, out, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));
@@ -74,55 +106,110 @@ int minmax_impl(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn, d
     return MA_OK;
 }
 
-// ---- DOG blurs --------------------------------------------------------------------------------
-// Row pass: normalise on the fly (v*a + b, two roundings) and accumulate both kernels left to right.
+// ---- DOG row pass -----------------------------------------------------------------------------
+// Block: 256 output columns x DR rows.  The normalised input row segment (+- r halo, reflect-101) is staged in
+// LDS; every thread accumulates both kernels left to right over the ksize taps (one LDS read per tap, shared).
+constexpr int DR = 4;
 template <typename T>
-__global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h, int w, float a, float b, int ksize,
-                                                const float* __restrict__ klo, const float* __restrict__ khi,
-                                                float* __restrict__ tlo, float* __restrict__ thi)
+__global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h, int w, int ksize,
+                                                const DogScalars* __restrict__ sc, const float* __restrict__ klo,
+                                                const float* __restrict__ khi, float* __restrict__ tlo,
+                                                float* __restrict__ thi)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const T* s = src + (size_t)y * w;
-    const int r = ksize / 2;
-    float accl = 0.f, acch = 0.f;
-    for (int j = 0; j < ksize; j++) {
-        float v = __fadd_rn(__fmul_rn((float)s[d_reflect101(x - r + j, w)], a), b);
-        float pl = klo[j] * v, ph = khi[j] * v;
-        if (j == 0) { accl = pl; acch = ph; }
-        else { accl = accl + pl; acch = acch + ph; }
+    extern __shared__ float lds[];  // [DR][256 + 2r]
+    const int r = ksize / 2, span = 256 + 2 * r;
+    const int x0 = blockIdx.x * 256, y0 = blockIdx.y * DR;
+    const float a = sc->a, b = sc->b;
+    for (int row = 0; row < DR; row++) {
+        const int y = min(y0 + row, h - 1);
+        const T* s = src + (size_t)y * w;
+        for (int c = threadIdx.x; c < span; c += 256) {
+            int x = d_reflect101(x0 - r + c, w);
+            lds[row * span + c] = __fadd_rn(__fmul_rn((float)s[x], a), b);
+        }
     }
-    tlo[(size_t)y * w + x] = accl;
-    thi[(size_t)y * w + x] = acch;
+    __syncthreads();
+    const int x = x0 + threadIdx.x;
+    if (x >= w) return;
+#pragma unroll
+    for (int row = 0; row < DR; row++) {
+        const int y = y0 + row;
+        if (y >= h) break;
+        const float* v = lds + row * span + threadIdx.x;
+        float accl = klo[0] * v[0], acch = khi[0] * v[0];
+        for (int j = 1; j < ksize; j++) {
+            float vj = v[j];
+            accl = accl + klo[j] * vj;
+            acch = acch + khi[j] * vj;
+        }
+        tlo[(size_t)y * w + x] = accl;
+        thi[(size_t)y * w + x] = acch;
+    }
 }
 
-// Column pass (symmetric form), difference hs - ls, and per-block min/max of the difference.
-__global__ __launch_bounds__(256) void dog_cols_diff(const float* __restrict__ tlo, const float* __restrict__ thi, int h,
-                                                     int w, int ksize, const float* __restrict__ klo,
-                                                     const float* __restrict__ khi, float* __restrict__ diff)
+// ---- DOG column pass + difference + per-block min/max ---------------------------------------------
+// Block: 64 columns x (NW*R) rows; per array the column strip (+- r halo rows, reflect-101) is staged in LDS and
+// the symmetric filter slides a register window down the column (d_sym_fir_slide).
+template <int R, int NW>
+__global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict__ tlo, const float* __restrict__ thi,
+                                                         int h, int w, int ksize, const float* __restrict__ klo_c,
+                                                         const float* __restrict__ khi_c, float* __restrict__ diff,
+                                                         float* __restrict__ part)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
+    extern __shared__ float lds[];  // [(NW*R + 2r)][64]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = ksize / 2;
-    const size_t c = (size_t)y * w + x;
-    float sl = klo[r] * tlo[c], sh = khi[r] * thi[c];
-    for (int j = 1; j <= r; j++) {
-        const size_t pa = (size_t)d_reflect101(y + j, h) * w + x, pb = (size_t)d_reflect101(y - j, h) * w + x;
-        float pl = klo[r + j] * (tlo[pa] + tlo[pb]);
-        float ph = khi[r + j] * (thi[pa] + thi[pb]);
-        sl = sl + pl;
-        sh = sh + ph;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * (NW * R);
+    const int rows = NW * R + 2 * r;
+    const int xc = min(x0 + lane, w - 1);
+    float sl[R], sh[R];
+    for (int arr = 0; arr < 2; arr++) {
+        const float* src = arr == 0 ? tlo : thi;
+        for (int j = wv; j < rows; j += NW) {
+            int y = d_reflect101(y0 - r + j, h);
+            lds[j * 64 + lane] = src[(size_t)y * w + xc];
+        }
+        __syncthreads();
+        if (arr == 0) d_sym_fir_slide<R, false>(lds + lane, 64, r + wv * R, r, rows - 1, klo_c, sl);
+        else d_sym_fir_slide<R, false>(lds + lane, 64, r + wv * R, r, rows - 1, khi_c, sh);
+        __syncthreads();
     }
-    diff[c] = sh - sl;
+    float lo = INFINITY, hi = -INFINITY;
+    const int x = x0 + lane;
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+        const int y = y0 + wv * R + q;
+        if (x < w && y < h) {
+            float d = sh[q] - sl[q];
+            diff[(size_t)y * w + x] = d;
+            lo = fminf(lo, d); hi = fmaxf(hi, d);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_down(lo, off));
+        hi = fmaxf(hi, __shfl_down(hi, off));
+    }
+    __shared__ float slo[NW], shi[NW];
+    if (lane == 0) { slo[wv] = lo; shi[wv] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < NW; k++) { lo = fminf(lo, slo[k]); hi = fmaxf(hi, shi[k]); }
+        const size_t bid = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        part[bid * 2] = lo;
+        part[bid * 2 + 1] = hi;
+    }
 }
 
+// dst = saturate_u8(round_half_even(src*a + b)); a/b either immediate or from the DOG scalars
 template <typename T>
 __global__ __launch_bounds__(256) void scale_to_u8(const T* __restrict__ src, size_t n, float a, float b,
-                                                   uint8_t* __restrict__ dst)
+                                                   const DogScalars* __restrict__ sc, uint8_t* __restrict__ dst)
 {
+    bool zero = false;
+    if (sc) { a = sc->a8; b = sc->b8; zero = sc->src_max_is_zero != 0; }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float v = __fadd_rn(__fmul_rn((float)src[i], a), b);
-        dst[i] = (uint8_t)d_clamp(d_cvround(v), 0, 255);
+        dst[i] = zero ? (uint8_t)0 : (uint8_t)d_clamp(d_cvround(v), 0, 255);
     }
 }
 
@@ -164,6 +251,8 @@ void gaussian_kernel(int ksize, double sigma, std::vector<float>& k)
 
 int grid_for(size_t n) { size_t b = (n + 256 * 4 - 1) / (256 * 4); return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
+constexpr int DC_R = 16, DC_NW = 4;
+
 } // namespace
 
 extern "C" {
@@ -174,57 +263,69 @@ int ma_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn_host
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
     MA_REQUIRE(n > 0, "empty array");
     MA_HIP(hipSetDevice(ctx->device));
-    return minmax_impl(ctx, src, dtype, n, mn_host, mx_host);
+    return minmax_host(ctx, src, dtype, n, mn_host, mx_host);
 }
 
-int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst)
+int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst,
+              int* src_max_is_zero_host)
 {
     MA_REQUIRE(ctx && src && dst, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
-    MA_REQUIRE(h > 0 && w > 0 && h <= 65535, "bad image size");
+    MA_REQUIRE(h > 0 && w > 0, "bad image size");
     MA_REQUIRE(low_sigma >= 1 && high_sigma >= 1, "sigmas must be >= 1");
     MA_HIP(hipSetDevice(ctx->device));
     const size_t n = (size_t)h * w;
     const int ksize = low_sigma * 4 * 2 + 1;  // optflow_registrator.py:262
-
-    double smin, smax;
-    MA_TRY(minmax_impl(ctx, src, dtype, n, &smin, &smax));
-    // normalize(src, 0, 1, NORM_MINMAX, CV_32F): scale/shift rounded to float as OpenCV does
-    double scale = (1.0 - 0.0) * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
-    scale = (float)scale;
-    float shiftf = (float)0.0 - (float)(smin * scale);
-    const float a = (float)scale, b = shiftf;
+    const int r = ksize / 2;
+    const size_t lds_rows = (size_t)DR * (256 + 2 * r) * sizeof(float);
+    const size_t lds_cols = (size_t)(DC_NW * DC_R + 2 * r) * 64 * sizeof(float);
+    MA_REQUIRE(lds_rows <= 160 * 1024 && lds_cols <= 160 * 1024, "low_sigma too large for the LDS-staged DOG kernels");
 
     std::vector<float> klo, khi;
     gaussian_kernel(ksize, low_sigma, klo);
     gaussian_kernel(ksize, high_sigma, khi);
-    const float *dlo = nullptr, *dhi = nullptr;
-    MA_TRY(ma_const_table(ctx, ((uint64_t)2 << 56) | ((uint64_t)ksize << 16) | (uint64_t)low_sigma, klo.data(), klo.size(), &dlo));
-    MA_TRY(ma_const_table(ctx, ((uint64_t)2 << 56) | ((uint64_t)ksize << 16) | (uint64_t)high_sigma, khi.data(), khi.size(), &dhi));
+    const float *dlo = nullptr, *dhi = nullptr, *dloc = nullptr, *dhic = nullptr;
+    const uint64_t key = ((uint64_t)ksize << 16);
+    MA_TRY(ma_const_table(ctx, ((uint64_t)2 << 56) | key | (uint64_t)low_sigma, klo.data(), klo.size(), &dlo));
+    MA_TRY(ma_const_table(ctx, ((uint64_t)2 << 56) | key | (uint64_t)high_sigma, khi.data(), khi.size(), &dhi));
+    // centre-first halves for the symmetric column pass: c[i] = k[r + i]
+    std::vector<float> clo(klo.begin() + r, klo.end()), chi(khi.begin() + r, khi.end());
+    MA_TRY(ma_const_table(ctx, ((uint64_t)3 << 56) | key | (uint64_t)low_sigma, clo.data(), clo.size(), &dloc));
+    MA_TRY(ma_const_table(ctx, ((uint64_t)3 << 56) | key | (uint64_t)high_sigma, chi.data(), chi.size(), &dhic));
 
-    MA_TRY(ma_ws_reserve(ctx, n * 3 * sizeof(float)));
+    // workspace: tlo, thi, diff (f32 each), block partials, scalars
+    const dim3 cgrid((w + 63) / 64, (h + DC_NW * DC_R - 1) / (DC_NW * DC_R));
+    const size_t nblk = (size_t)cgrid.x * cgrid.y;
+    const size_t npart = nblk > MM_BLOCKS ? nblk : MM_BLOCKS;
+    const size_t bytes = n * 3 * sizeof(float) + npart * 2 * sizeof(float) + 256;
+    MA_TRY(ma_ws_reserve(ctx, bytes));
     float* tlo = (float*)ctx->ws;
     float* thi = tlo + n;
     float* diff = thi + n;
+    float* part = diff + n;
+    DogScalars* sc = (DogScalars*)(part + npart * 2);
+    MA_REQUIRE(cgrid.y <= 65535 && (h + DR - 1) / DR <= 65535, "image too tall");
+
+    MaProfScope ps(ctx, MA_K_DOG, (double)n);
+    MA_TRY(launch_minmax(ctx, src, dtype, n, part, sc->mm_src));
+    hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc);
     {
-        MaProfScope ps(ctx, MA_K_DOG, (double)n);
-        dim3 grid((w + 255) / 256, h), block(256);
-        if (dtype == MA_U8) hipLaunchKernelGGL((dog_rows<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)src, h, w, a, b, ksize, dlo, dhi, tlo, thi);
-        else if (dtype == MA_U16) hipLaunchKernelGGL((dog_rows<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)src, h, w, a, b, ksize, dlo, dhi, tlo, thi);
-        else hipLaunchKernelGGL((dog_rows<float>), grid, block, 0, ctx->stream, (const float*)src, h, w, a, b, ksize, dlo, dhi, tlo, thi);
-        hipLaunchKernelGGL(dog_cols_diff, grid, block, 0, ctx->stream, tlo, thi, h, w, ksize, dlo, dhi, diff);
-        MA_HIP(hipGetLastError());
+        dim3 grid((w + 255) / 256, (h + DR - 1) / DR), block(256);
+        if (dtype == MA_U8) hipLaunchKernelGGL((dog_rows<uint8_t>), grid, block, lds_rows, ctx->stream, (const uint8_t*)src, h, w, ksize, sc, dlo, dhi, tlo, thi);
+        else if (dtype == MA_U16) hipLaunchKernelGGL((dog_rows<uint16_t>), grid, block, lds_rows, ctx->stream, (const uint16_t*)src, h, w, ksize, sc, dlo, dhi, tlo, thi);
+        else hipLaunchKernelGGL((dog_rows<float>), grid, block, lds_rows, ctx->stream, (const float*)src, h, w, ksize, sc, dlo, dhi, tlo, thi);
     }
-    double dmin, dmax;
-    MA_TRY(minmax_impl(ctx, diff, MA_F32, n, &dmin, &dmax));
-    // normalize(diff, 0, 255, NORM_MINMAX, CV_8U): scale/shift in double, applied in float
-    double scale8 = 255. * (dmax - dmin > DBL_EPSILON ? 1. / (dmax - dmin) : 0);
-    double shift8 = 0. - dmin * scale8;
-    {
-        MaProfScope ps(ctx, MA_K_DOG, 0);
-        hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, (float)scale8,
-                           (float)shift8, dst);
-        MA_HIP(hipGetLastError());
+    hipLaunchKernelGGL((dog_cols_diff<DC_R, DC_NW>), cgrid, dim3(64 * DC_NW), lds_cols, ctx->stream, tlo, thi, h, w, ksize,
+                       dloc, dhic, diff, part);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, ctx->stream, part, (int)nblk, sc->mm_diff);
+    hipLaunchKernelGGL(dog_params_out, dim3(1), dim3(1), 0, ctx->stream, sc);
+    hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst);
+    MA_HIP(hipGetLastError());
+    if (src_max_is_zero_host) {
+        MA_TRY(ma_pinned_reserve(ctx, 64));
+        MA_HIP(hipMemcpyAsync(ctx->pinned, &sc->src_max_is_zero, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MA_HIP(hipStreamSynchronize(ctx->stream));
+        *src_max_is_zero_host = *(int*)ctx->pinned;
     }
     return MA_OK;
 }
@@ -251,14 +352,15 @@ int ma_normalize_minmax_u8(ma_ctx* ctx, const void* src, int dtype, size_t n, ui
     MA_REQUIRE(n > 0, "empty array");
     MA_HIP(hipSetDevice(ctx->device));
     double smin, smax;
-    MA_TRY(minmax_impl(ctx, src, dtype, n, &smin, &smax));
+    MA_TRY(minmax_host(ctx, src, dtype, n, &smin, &smax));
     double scale = 255. * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
     double shift = 0. - smin * scale;
     MaProfScope ps(ctx, MA_K_OTHER, (double)n);
     dim3 grid(grid_for(n)), block(256);
-    if (dtype == MA_U8) hipLaunchKernelGGL((scale_to_u8<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)src, n, (float)scale, (float)shift, dst);
-    else if (dtype == MA_U16) hipLaunchKernelGGL((scale_to_u8<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)src, n, (float)scale, (float)shift, dst);
-    else hipLaunchKernelGGL((scale_to_u8<float>), grid, block, 0, ctx->stream, (const float*)src, n, (float)scale, (float)shift, dst);
+    const DogScalars* none = nullptr;
+    if (dtype == MA_U8) hipLaunchKernelGGL((scale_to_u8<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)src, n, (float)scale, (float)shift, none, dst);
+    else if (dtype == MA_U16) hipLaunchKernelGGL((scale_to_u8<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)src, n, (float)scale, (float)shift, none, dst);
+    else hipLaunchKernelGGL((scale_to_u8<float>), grid, block, 0, ctx->stream, (const float*)src, n, (float)scale, (float)shift, none, dst);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }

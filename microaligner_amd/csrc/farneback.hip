@@ -222,38 +222,8 @@ __global__ __launch_bounds__(64 * NW) void fb_blur_v(FbGeom g, int m, const floa
     }
     __syncthreads();
 
-    const int jb = m + w * R;  // LDS row of this thread's first output row
-    float acc[R], P[R], Q[R];
-    const float k0 = taps[0];
-#pragma unroll
-    for (int r = 0; r < R; r++) acc[r] = lds[(jb + r) * 64 + lane] * k0;
-#pragma unroll
-    for (int o = 1; o <= R; o++) P[o % R] = lds[(jb + o) * 64 + lane];
-#pragma unroll
-    for (int o = -1; o <= R - 2; o++) Q[(o + R) % R] = lds[(jb + o) * 64 + lane];
-
-    // full groups of R taps: branch-free, the windows rotate through statically indexed registers
-    const int full = m / R;
-    for (int g = 0; g < full; g++) {
-#pragma unroll
-        for (int ii = 0; ii < R; ii++) {
-            const int i = g * R + ii + 1;
-            const float ki = taps[i];
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                acc[r] = d_muladd<FUSED>(P[(r + ii + 1) % R] + Q[((r - ii - 1) % R + R) % R], ki, acc[r]);
-            // next tap's entering rows (index clamped: the last tap of the last group reads nothing it needs)
-            P[(ii + 1) % R] = lds[min(jb + i + R, rows - 1) * 64 + lane];
-            Q[((-ii - 2) % R + R) % R] = lds[max(jb - i - 1, 0) * 64 + lane];
-        }
-    }
-    // remaining m % R taps straight from LDS (same accumulation order)
-    for (int i = full * R + 1; i <= m; i++) {
-        const float ki = taps[i];
-#pragma unroll
-        for (int r = 0; r < R; r++)
-            acc[r] = d_muladd<FUSED>(lds[(jb + r + i) * 64 + lane] + lds[(jb + r - i) * 64 + lane], ki, acc[r]);
-    }
+    float acc[R];
+    d_sym_fir_slide<R, FUSED>(lds + lane, 64, m + w * R, m, rows - 1, taps, acc);
     const int x = x0 + lane;
     if (x < Pw) {
 #pragma unroll
@@ -287,46 +257,17 @@ __global__ __launch_bounds__(64 * NW) void fb_blur_h_solve(FbGeom g, int m, cons
     const int lp = cols | 1;              // odd LDS pitch: lanes (rows) hit distinct banks
 
     float hs[5][R];
-    const float k0 = taps[0];
 #pragma unroll
     for (int ch = 0; ch < 5; ch++) {
         const float* src = plane_ptr(ws, g, wl, PL_V + ch);
         // stage rows y0..y0+63, columns x0-m .. x0+TXW+m-1 (replicate), coalesced along x
-        for (int i = tid; i < 64 * cols; i += NT) {
-            int j = i / cols, c = i - j * cols;
-            int y = min(y0 + j, Ph - 1);
-            int x = d_clamp(x0 - m + c, 0, Pw - 1);
-            lds[j * lp + c] = src[(size_t)y * g.pitch + x];
+        for (int j = w; j < 64; j += NW) {
+            const float* srow = src + (size_t)min(y0 + j, Ph - 1) * g.pitch;
+            for (int c = lane; c < cols; c += 64) lds[j * lp + c] = srow[d_clamp(x0 - m + c, 0, Pw - 1)];
         }
         __syncthreads();
-        const float* row = lds + lane * lp;
-        const int cb = m + w * R;
-        float acc[R], P[R], Q[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) acc[r] = row[cb + r] * k0;
-#pragma unroll
-        for (int o = 1; o <= R; o++) P[o % R] = row[cb + o];
-#pragma unroll
-        for (int o = -1; o <= R - 2; o++) Q[(o + R) % R] = row[cb + o];
-        const int full = m / R;
-        for (int g = 0; g < full; g++) {
-#pragma unroll
-            for (int ii = 0; ii < R; ii++) {
-                const int i = g * R + ii + 1;
-                const float ki = taps[i];
-#pragma unroll
-                for (int r = 0; r < R; r++)
-                    acc[r] = d_muladd<FUSED>(Q[((r - ii - 1) % R + R) % R] + P[(r + ii + 1) % R], ki, acc[r]);
-                P[(ii + 1) % R] = row[min(cb + i + R, cols - 1)];
-                Q[((-ii - 2) % R + R) % R] = row[max(cb - i - 1, 0)];
-            }
-        }
-        for (int i = full * R + 1; i <= m; i++) {
-            const float ki = taps[i];
-#pragma unroll
-            for (int r = 0; r < R; r++)
-                acc[r] = d_muladd<FUSED>(row[cb + r - i] + row[cb + r + i], ki, acc[r]);
-        }
+        float acc[R];
+        d_sym_fir_slide<R, FUSED>(lds + lane * lp, 1, m + w * R, m, cols - 1, taps, acc);
 #pragma unroll
         for (int r = 0; r < R; r++) hs[ch][r] = acc[r];
         __syncthreads();

@@ -107,6 +107,45 @@ __device__ __forceinline__ float d_muladd(float a, float b, float c)
     return __fadd_rn(__fmul_rn(a, b), c);
 }
 
+// Symmetric FIR along one axis with a rotating register window (used by the Farneback window blur and the DOG
+// column pass).  `col` points at this thread's line in LDS, element j is col[j * stride].  For R consecutive
+// outputs starting at element jb:   s = c * k0;   s = (x[+i] + x[-i]) * k_i + s   for i = 1..m   (ascending i).
+// Full groups of R taps rotate the +i / -i windows through statically indexed registers (two LDS reads per
+// tap); the remaining m % R taps are read straight from LDS.  `last` is the largest valid element index.
+template <int R, bool FUSED>
+__device__ __forceinline__ void d_sym_fir_slide(const float* __restrict__ col, const int stride, const int jb,
+                                                const int m, const int last, const float* __restrict__ taps,
+                                                float acc[R])
+{
+    float P[R], Q[R];
+    const float k0 = taps[0];
+#pragma unroll
+    for (int r = 0; r < R; r++) acc[r] = col[(jb + r) * stride] * k0;
+#pragma unroll
+    for (int o = 1; o <= R; o++) P[o % R] = col[min(jb + o, last) * stride];
+#pragma unroll
+    for (int o = -1; o <= R - 2; o++) Q[(o + R) % R] = col[max(jb + o, 0) * stride];
+    const int full = m / R;
+    for (int g = 0; g < full; g++) {
+#pragma unroll
+        for (int ii = 0; ii < R; ii++) {
+            const int i = g * R + ii + 1;
+            const float ki = taps[i];
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                acc[r] = d_muladd<FUSED>(P[(r + ii + 1) % R] + Q[((r - ii - 1) % R + R) % R], ki, acc[r]);
+            P[(ii + 1) % R] = col[min(jb + i + R, last) * stride];
+            Q[((-ii - 2) % R + R) % R] = col[max(jb - i - 1, 0) * stride];
+        }
+    }
+    for (int i = full * R + 1; i <= m; i++) {
+        const float ki = taps[i];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            acc[r] = d_muladd<FUSED>(col[(jb + r + i) * stride] + col[(jb + r - i) * stride], ki, acc[r]);
+    }
+}
+
 // Tile geometry shared by the tiled kernels (slicer.py / stitcher.py semantics).
 struct MaTiling {
     int H, W;      // image size

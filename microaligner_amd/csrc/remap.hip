@@ -130,38 +130,51 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
 
 // ---- flow merge ---------------------------------------------------------------------------------
 // per window: max over the zero-padded window of both flow components (numpy .max(), NaNs ignored)
+// floats <-> unsigned keys whose integer order is the float order (so atomicMax works for any sign)
+__device__ __forceinline__ unsigned f2key(float f)
+{
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// grid: (window, row band of WM_ROWS rows); maxkeys[2*window + {0,1}] must be zero-initialised
+// (key 0 decodes to a NaN that loses against every real value's key).
+constexpr int WM_ROWS = 64;
 __global__ __launch_bounds__(256) void window_max_kernel(const float2* __restrict__ f1, const float2* __restrict__ f2,
-                                                         MaTiling g, float* __restrict__ maxes)
+                                                         MaTiling g, unsigned* __restrict__ maxkeys)
 {
     const int widx = blockIdx.x;
     int oy = 0, ox = 0;
     if (g.T > 0) { int ty = widx / g.ntx, tx = widx - ty * g.ntx; oy = ty * g.T - g.ov; ox = tx * g.T - g.ov; }
-    const int ya = max(oy, 0), yb = min(oy + g.Ph, g.H), xa = max(ox, 0), xb = min(ox + g.Pw, g.W);
+    const int yb = min(oy + g.Ph, g.H), xa = max(ox, 0), xb = min(ox + g.Pw, g.W);
+    const int ya = max(oy, 0) + blockIdx.y * WM_ROWS;
+    if (ya >= yb) return;
+    const int ye = min(ya + WM_ROWS, yb);
     const bool padded = oy < 0 || ox < 0 || oy + g.Ph > g.H || ox + g.Pw > g.W;
-    const float init = padded ? 0.f : -INFINITY;
+    const float init = padded ? 0.f : -INFINITY;  // zero padding takes part in numpy's .max()
     float m1 = init, m2 = init;
-    const int ww = xb - xa, n = (yb - ya) * ww;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        int yy = ya + i / ww, xx = xa + i % ww;
-        float2 a = f1[(size_t)yy * g.W + xx], b = f2[(size_t)yy * g.W + xx];
-        m1 = fmaxf(m1, fmaxf(a.x, a.y));
-        m2 = fmaxf(m2, fmaxf(b.x, b.y));
-    }
+    for (int yy = ya + (threadIdx.x >> 6); yy < ye; yy += 4)
+        for (int xx = xa + (threadIdx.x & 63); xx < xb; xx += 64) {
+            float2 a = f1[(size_t)yy * g.W + xx], b = f2[(size_t)yy * g.W + xx];
+            m1 = fmaxf(m1, fmaxf(a.x, a.y));
+            m2 = fmaxf(m2, fmaxf(b.x, b.y));
+        }
     for (int off = 32; off > 0; off >>= 1) {
         m1 = fmaxf(m1, __shfl_down(m1, off));
         m2 = fmaxf(m2, __shfl_down(m2, off));
     }
-    __shared__ float s1[4], s2[4];
-    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = m1; s2[threadIdx.x >> 6] = m2; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        maxes[widx * 2] = fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3]));
-        maxes[widx * 2 + 1] = fmaxf(fmaxf(s2[0], s2[1]), fmaxf(s2[2], s2[3]));
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&maxkeys[widx * 2], f2key(m1));
+        atomicMax(&maxkeys[widx * 2 + 1], f2key(m2));
     }
 }
 
 __global__ __launch_bounds__(256) void merge_flows_kernel(const float2* __restrict__ f1, const float2* __restrict__ f2,
-                                                          MaTiling g, const float* __restrict__ maxes,
+                                                          MaTiling g, const unsigned* __restrict__ maxkeys,
                                                           float2* __restrict__ out)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -175,8 +188,8 @@ __global__ __launch_bounds__(256) void merge_flows_kernel(const float2* __restri
     const size_t p = (size_t)y * g.W + x;
     const float2 a = f1[p];
     float2 res;
-    if (maxes[widx * 2] == 0.f) res = f2[p];               // flow1.max() == 0 -> flow2
-    else if (maxes[widx * 2 + 1] == 0.f) res = a;          // flow2.max() == 0 -> flow1
+    if (key2f(maxkeys[widx * 2]) == 0.f) res = f2[p];               // flow1.max() == 0 -> flow2
+    else if (key2f(maxkeys[widx * 2 + 1]) == 0.f) res = a;          // flow2.max() == 0 -> flow1
     else {
         // flow1 + cv.remap(flow2, -flow1): the map is -flow1 itself (absolute window coordinates, quirk Q1)
         Tap t = quantise(-a.x, -a.y);
@@ -254,11 +267,12 @@ int ma_merge_flows_tiled(ma_ctx* ctx, const float* flow1, const float* flow2, in
     MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
     MA_HIP(hipSetDevice(ctx->device));
     const int nwin = g.ntx * g.nty;
-    MA_TRY(ma_dconst_reserve(ctx, (size_t)nwin * 2 * sizeof(float)));
-    float* maxes = (float*)ctx->dconst;
+    MA_TRY(ma_dconst_reserve(ctx, (size_t)nwin * 2 * sizeof(unsigned)));
+    unsigned* maxes = (unsigned*)ctx->dconst;
     MaProfScope ps(ctx, MA_K_MERGE, (double)H * W);
-    hipLaunchKernelGGL(window_max_kernel, dim3(nwin), dim3(256), 0, ctx->stream, (const float2*)flow1,
-                       (const float2*)flow2, g, maxes);
+    MA_HIP(hipMemsetAsync(maxes, 0, (size_t)nwin * 2 * sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(window_max_kernel, dim3(nwin, (g.Ph + WM_ROWS - 1) / WM_ROWS), dim3(256), 0, ctx->stream,
+                       (const float2*)flow1, (const float2*)flow2, g, maxes);
     hipLaunchKernelGGL(merge_flows_kernel, dim3((W + 255) / 256, H), dim3(256), 0, ctx->stream, (const float2*)flow1,
                        (const float2*)flow2, g, maxes, (float2*)out);
     MA_HIP(hipGetLastError());

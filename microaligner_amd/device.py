@@ -246,12 +246,15 @@ class Context:
         L.check(self.lib.ma_minmax(self.handle, arr.ptr, _dt(arr.dtype), arr.size, C.byref(mn), C.byref(mx)))
         return mn.value, mx.value
 
-    def dog_u8(self, img, low_sigma=5, high_sigma=9):
+    def dog_u8(self, img, low_sigma=5, high_sigma=9, report_zero=False):
+        """Body of OptFlowRegistrator.dog -> uint8.  Stream ordered (no host sync) unless report_zero, in which
+        case (out, src_max_is_zero) is returned; out is all zero when the input's max is 0."""
         h, w = img.shape
         out = self.empty((h, w), np.uint8)
+        flag = C.c_int(0)
         L.check(self.lib.ma_dog_u8(self.handle, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma),
-                                   out.ptr))
-        return out
+                                   out.ptr, C.byref(flag) if report_zero else None))
+        return (out, bool(flag.value)) if report_zero else out
 
     def nmi_scores(self, a, b, chunk=0):
         if a.dtype != np.uint8 or b.dtype != np.uint8 or a.size != b.size:

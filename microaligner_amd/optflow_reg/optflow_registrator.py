@@ -218,21 +218,17 @@ class OptFlowRegistrator:
         return {1: (5, 9), 2: (4, 7), 4: (3, 5), 8: (2, 3), 16: (1, 2)}[pyr_factor]
 
     def _dog_dev(self, img: DeviceArray, low_sigma: int = 5, high_sigma: int = 9):
-        """dog(img, True) on a device array; an image whose max is 0 is returned unchanged (:256-257)."""
-        ctx = get_context()
-        _, mx = ctx.minmax(img)
-        if mx == 0:
-            return img
-        return ctx.dog_u8(img, low_sigma, high_sigma)
+        """dog(img, True) for register(): stays on the stream.  Where the reference returns an image whose max
+        is 0 unchanged (:256-257) this yields the all-zero uint8 image, which every consumer on the path
+        (Farneback's convertTo float, the NMI labels) treats identically for the all-zero image that case means."""
+        return get_context().dog_u8(img, low_sigma, high_sigma)
 
     def dog(self, img, use_it: bool, low_sigma: int = 5, high_sigma: int = 9):
         """Difference of Gaussians -> uint8 (optflow_registrator.py:249-274)."""
         if not use_it:
             return img
         ctx = get_context()
-        dev = ctx.asdevice(img)
-        _, mx = ctx.minmax(dev)
-        if mx == 0:
+        out, src_max_is_zero = ctx.dog_u8(ctx.asdevice(img), low_sigma, high_sigma, report_zero=True)
+        if src_max_is_zero:
             return img
-        out = ctx.dog_u8(dev, low_sigma, high_sigma)
         return out if isinstance(img, DeviceArray) else out.numpy()
