@@ -160,7 +160,9 @@ def main():
     if rank == 0:
         prof = ctx.profile_get()
         iters, esz = reg.num_iterations, 4
-        kernels = {k: roofline_entry(k, v, iters, esz) for k, v in prof.items()}
+        # with use_dog the Farneback inputs are the uint8 DOG images (1 B/px), not the f32 level images
+        fb_esz = 1 if reg.use_dog else esz
+        kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz) for k, v in prof.items()}
         kernels = {k: v for k, v in kernels.items() if v}
         total_kernel_ms = sum(v["ms"] for v in prof.values())
         dominant = max(kernels, key=lambda k: prof[k]["ms"]) if kernels else None

@@ -159,19 +159,24 @@ __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict
     extern __shared__ float lds[];  // [(NW*R + 2r)][64]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = ksize / 2;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * (NW * R);
-    const int rows = NW * R + 2 * r;
+    // y-fastest work list walked contiguously per XCD (d_xcd_work_item): halo rows come from the XCD's L2
+    const int nbx = (w + 63) / 64, nby = (h + NW * R - 1) / (NW * R);
+    const int item = d_xcd_work_item(blockIdx.x, nbx * nby);
+    if (item >= nbx * nby) return;
+    const int x0 = (item / nby) * 64, y0 = (item % nby) * (NW * R);
+    constexpr int G = 2;  // guard rows (d_sym_fir_slide contract)
+    const int rows = NW * R + 2 * r + 2 * G;
     const int xc = min(x0 + lane, w - 1);
     float sl[R], sh[R];
     for (int arr = 0; arr < 2; arr++) {
         const float* src = arr == 0 ? tlo : thi;
         for (int j = wv; j < rows; j += NW) {
-            int y = d_reflect101(y0 - r + j, h);
+            int y = d_reflect101(y0 - r - G + j, h);
             lds[j * 64 + lane] = src[(size_t)y * w + xc];
         }
         __syncthreads();
-        if (arr == 0) d_sym_fir_slide<R, false>(lds + lane, 64, r + wv * R, r, rows - 1, klo_c, sl);
-        else d_sym_fir_slide<R, false>(lds + lane, 64, r + wv * R, r, rows - 1, khi_c, sh);
+        if (arr == 0) d_sym_fir_slide_pk<R, false, true>(lds + lane, G + r + wv * R, r, klo_c, sl);
+        else d_sym_fir_slide_pk<R, false, true>(lds + lane, G + r + wv * R, r, khi_c, sh);
         __syncthreads();
     }
     float lo = INFINITY, hi = -INFINITY;
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < NW; k++) { lo = fminf(lo, slo[k]); hi = fmaxf(hi, shi[k]); }
-        const size_t bid = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const size_t bid = (size_t)item;
         part[bid * 2] = lo;
         part[bid * 2 + 1] = hi;
     }
@@ -278,7 +283,7 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     const int ksize = low_sigma * 4 * 2 + 1;  // optflow_registrator.py:262
     const int r = ksize / 2;
     const size_t lds_rows = (size_t)DR * (256 + 2 * r) * sizeof(float);
-    const size_t lds_cols = (size_t)(DC_NW * DC_R + 2 * r) * 64 * sizeof(float);
+    const size_t lds_cols = (size_t)(DC_NW * DC_R + 2 * r + 4) * 64 * sizeof(float);
     MA_REQUIRE(lds_rows <= 160 * 1024 && lds_cols <= 160 * 1024, "low_sigma too large for the LDS-staged DOG kernels");
 
     std::vector<float> klo, khi;
@@ -289,7 +294,8 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     MA_TRY(ma_const_table(ctx, ((uint64_t)2 << 56) | key | (uint64_t)low_sigma, klo.data(), klo.size(), &dlo));
     MA_TRY(ma_const_table(ctx, ((uint64_t)2 << 56) | key | (uint64_t)high_sigma, khi.data(), khi.size(), &dhi));
     // centre-first halves for the symmetric column pass: c[i] = k[r + i]
-    std::vector<float> clo(klo.begin() + r, klo.end()), chi(khi.begin() + r, khi.end());
+    std::vector<float> clo = ma_layout_taps(std::vector<float>(klo.begin() + r, klo.end()));
+    std::vector<float> chi = ma_layout_taps(std::vector<float>(khi.begin() + r, khi.end()));
     MA_TRY(ma_const_table(ctx, ((uint64_t)3 << 56) | key | (uint64_t)low_sigma, clo.data(), clo.size(), &dloc));
     MA_TRY(ma_const_table(ctx, ((uint64_t)3 << 56) | key | (uint64_t)high_sigma, chi.data(), chi.size(), &dhic));
 
@@ -304,7 +310,7 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     float* diff = thi + n;
     float* part = diff + n;
     DogScalars* sc = (DogScalars*)(part + npart * 2);
-    MA_REQUIRE(cgrid.y <= 65535 && (h + DR - 1) / DR <= 65535, "image too tall");
+    MA_REQUIRE((h + DR - 1) / DR <= 65535, "image too tall");
 
     MaProfScope ps(ctx, MA_K_DOG, (double)n);
     MA_TRY(launch_minmax(ctx, src, dtype, n, part, sc->mm_src));
@@ -315,8 +321,8 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
         else if (dtype == MA_U16) hipLaunchKernelGGL((dog_rows<uint16_t>), grid, block, lds_rows, ctx->stream, (const uint16_t*)src, h, w, ksize, sc, dlo, dhi, tlo, thi);
         else hipLaunchKernelGGL((dog_rows<float>), grid, block, lds_rows, ctx->stream, (const float*)src, h, w, ksize, sc, dlo, dhi, tlo, thi);
     }
-    hipLaunchKernelGGL((dog_cols_diff<DC_R, DC_NW>), cgrid, dim3(64 * DC_NW), lds_cols, ctx->stream, tlo, thi, h, w, ksize,
-                       dloc, dhic, diff, part);
+    hipLaunchKernelGGL((dog_cols_diff<DC_R, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
+                       ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
     hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, ctx->stream, part, (int)nblk, sc->mm_diff);
     hipLaunchKernelGGL(dog_params_out, dim3(1), dim3(1), 0, ctx->stream, sc);
     hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst);

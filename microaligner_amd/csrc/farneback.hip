@@ -204,26 +204,52 @@ __global__ __launch_bounds__(K1_THREADS) void fb_polyexp_m0(const T* __restrict_
 // ---------------------------------------------------------------------------------------------
 template <int R, int NW, bool FUSED>
 __global__ __launch_bounds__(64 * NW) void fb_blur_v(FbGeom g, int m, const float* __restrict__ taps,
-                                                     float* __restrict__ ws)
+                                                     float* __restrict__ ws, int nplanes)
 {
     extern __shared__ float lds[];  // [(NW*R + 2m)][64]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * (NW * R);
-    const int wl = blockIdx.z / 5, ch = blockIdx.z - wl * 5;
     const int Ph = g.t.Ph, Pw = g.t.Pw;
+    // work list ordered y-fastest inside a column strip, walked contiguously per XCD: the 2m halo rows that
+    // vertically adjacent blocks share are then served by that XCD's L2 instead of being re-fetched
+    const int nbx = (Pw + 63) / 64, nby = (Ph + NW * R - 1) / (NW * R);
+    const int item = d_xcd_work_item(blockIdx.x, nbx * nby * nplanes);
+    if (item >= nbx * nby * nplanes) return;
+    const int by = item % nby, bx = (item / nby) % nbx, bz = item / (nby * nbx);
+    const int x0 = bx * 64, y0 = by * (NW * R);
+    const int wl = bz / 5, ch = bz - wl * 5;
     const float* src = plane_ptr(ws, g, wl, PL_M + ch);
     float* dst = plane_ptr(ws, g, wl, PL_V + ch);
 
-    const int rows = NW * R + 2 * m;
+    constexpr int G = 2;  // guard rows on either side (d_sym_fir_slide contract)
+    const int rows = NW * R + 2 * m + 2 * G;
     const int xc = min(x0 + lane, Pw - 1);
-    for (int j = w; j < rows; j += NW) {
-        int y = d_clamp(y0 - m + j, 0, Ph - 1);
-        lds[j * 64 + lane] = src[(size_t)y * g.pitch + xc];
+#ifndef MA_ABL_NOSTAGE
+    {
+        // rows in batches of SB per wave: all SB global loads are issued before the first LDS store
+#ifndef MA_BV_SB
+#define MA_BV_SB 42
+#endif
+        constexpr int SB = MA_BV_SB;
+        const float* scol = src + xc;
+        for (int j0 = w; j0 < rows; j0 += NW * SB) {
+            float v[SB];
+#pragma unroll
+            for (int k = 0; k < SB; k++)
+                v[k] = scol[(size_t)d_clamp(y0 - m - G + j0 + NW * k, 0, Ph - 1) * g.pitch];
+#pragma unroll
+            for (int k = 0; k < SB; k++)
+                if (j0 + NW * k < rows) lds[(j0 + NW * k) * 64 + lane] = v[k];
+        }
     }
+#endif
     __syncthreads();
 
     float acc[R];
-    d_sym_fir_slide<R, FUSED>(lds + lane, 64, m + w * R, m, rows - 1, taps, acc);
+#ifndef MA_ABL_NOFIR
+    d_sym_fir_slide_pk<R, FUSED, true>(lds + lane, G + m + w * R, m, taps, acc);
+#else
+    for (int r = 0; r < R; r++) acc[r] = lds[(G + m + w * R + r) * 64 + lane];
+#endif
     const int x = x0 + lane;
     if (x < Pw) {
 #pragma unroll
@@ -240,20 +266,29 @@ __global__ __launch_bounds__(64 * NW) void fb_blur_v(FbGeom g, int m, const floa
 // through LDS so that all global traffic (R0, R1 gather, M / flow stores) is coalesced along x.
 // Block: 64 rows x (NW*R) columns.
 // ---------------------------------------------------------------------------------------------
+#ifndef MA_BH_WAVES
+#define MA_BH_WAVES 6
+#endif
 template <int R, int NW, bool FUSED>
-__global__ __launch_bounds__(64 * NW) void fb_blur_h_solve(FbGeom g, int m, const float* __restrict__ taps,
+__global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g, int m, const float* __restrict__ taps,
                                                            float* __restrict__ ws, int last,
-                                                           float* __restrict__ flow_out)
+                                                           float* __restrict__ flow_out, int nwin)
 {
     extern __shared__ float lds[];
     constexpr int TXW = NW * R;           // output columns per block
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
-    const int x0 = blockIdx.x * TXW, y0 = blockIdx.y * 64;
-    const int wl = blockIdx.z;
     const int Ph = g.t.Ph, Pw = g.t.Pw;
-    const int cols = TXW + 2 * m;
+    // x-fastest work list walked contiguously per XCD (see fb_blur_v): horizontally adjacent blocks share 2m columns
+    const int nbx = (Pw + TXW - 1) / TXW, nby = (Ph + 63) / 64;
+    const int item = d_xcd_work_item(blockIdx.x, nbx * nby * nwin);
+    if (item >= nbx * nby * nwin) return;
+    const int bx = item % nbx, by = (item / nbx) % nby;
+    const int x0 = bx * TXW, y0 = by * 64;
+    const int wl = item / (nbx * nby);
+    constexpr int G = 2;  // guard columns on either side (d_sym_fir_slide contract)
+    const int cols = TXW + 2 * m + 2 * G;
     const int lp = cols | 1;              // odd LDS pitch: lanes (rows) hit distinct banks
 
     float hs[5][R];
@@ -261,13 +296,39 @@ __global__ __launch_bounds__(64 * NW) void fb_blur_h_solve(FbGeom g, int m, cons
     for (int ch = 0; ch < 5; ch++) {
         const float* src = plane_ptr(ws, g, wl, PL_V + ch);
         // stage rows y0..y0+63, columns x0-m .. x0+TXW+m-1 (replicate), coalesced along x
-        for (int j = w; j < 64; j += NW) {
-            const float* srow = src + (size_t)min(y0 + j, Ph - 1) * g.pitch;
-            for (int c = lane; c < cols; c += 64) lds[j * lp + c] = srow[d_clamp(x0 - m + c, 0, Pw - 1)];
+#ifndef MA_ABL_NOSTAGE
+        if (cols <= 192) {
+            // 64/NW rows x 3 column chunks per wave, every load issued before the first LDS store
+            constexpr int RW = 64 / NW;
+            float v[RW][3];
+            int xi[3];
+#pragma unroll
+            for (int q = 0; q < 3; q++) xi[q] = d_clamp(x0 - m - G + lane + 64 * q, 0, Pw - 1);
+#pragma unroll
+            for (int k = 0; k < RW; k++) {
+                const float* srow = src + (size_t)min(y0 + w + NW * k, Ph - 1) * g.pitch;
+#pragma unroll
+                for (int q = 0; q < 3; q++) v[k][q] = srow[xi[q]];
+            }
+#pragma unroll
+            for (int k = 0; k < RW; k++)
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    if (lane + 64 * q < cols) lds[(w + NW * k) * lp + lane + 64 * q] = v[k][q];
+        } else {
+            for (int j = w; j < 64; j += NW) {
+                const float* srow = src + (size_t)min(y0 + j, Ph - 1) * g.pitch;
+                for (int c = lane; c < cols; c += 64) lds[j * lp + c] = srow[d_clamp(x0 - m - G + c, 0, Pw - 1)];
+            }
         }
+#endif
         __syncthreads();
         float acc[R];
-        d_sym_fir_slide<R, FUSED>(lds + lane * lp, 1, m + w * R, m, cols - 1, taps, acc);
+#ifndef MA_ABL_NOFIR
+        d_sym_fir_slide_pk<R, FUSED, false>(lds + lane * lp, G + m + w * R, m, taps, acc);
+#else
+        for (int r = 0; r < R; r++) acc[r] = lds[lane * lp + G + m + w * R + r];
+#endif
 #pragma unroll
         for (int r = 0; r < R; r++) hs[ch][r] = acc[r];
         __syncthreads();
@@ -280,6 +341,14 @@ __global__ __launch_bounds__(64 * NW) void fb_blur_h_solve(FbGeom g, int m, cons
     const float* R0p = plane_ptr(ws, g, wl, PL_R0);
     const float* R1p = plane_ptr(ws, g, wl, PL_R1);
     float* Mp = plane_ptr(ws, g, wl, PL_M);
+#ifdef MA_ABL_NOFINAL
+    {
+        float s = 0;
+        for (int ch = 0; ch < 5; ch++) for (int r = 0; r < R; r++) s += hs[ch][r];
+        if (s == 123.456f) Mp[tid] = s;
+        return;
+    }
+#endif
     for (int half = 0; half < 2; half++) {
         if ((lane >> 5) == half) {
 #pragma unroll
@@ -355,7 +424,7 @@ __global__ void fb_blur_v_simple(FbGeom g, int m, const float* __restrict__ taps
     for (int i = 1; i <= m; i++) {
         float dn = src[(size_t)min(y + i, g.t.Ph - 1) * g.pitch + x];
         float up = src[(size_t)max(y - i, 0) * g.pitch + x];
-        s = d_muladd<FUSED>(dn + up, taps[i], s);
+        s = d_muladd<FUSED>(dn + up, MA_TAP(taps, i), s);
     }
     dst[(size_t)y * g.pitch + x] = s;
 }
@@ -372,7 +441,7 @@ __global__ void fb_blur_h_solve_simple(FbGeom g, int m, const float* __restrict_
     for (int ch = 0; ch < 5; ch++) {
         const float* src = plane_ptr(ws, g, wl, PL_V + ch) + (size_t)y * g.pitch;
         float s = src[x] * taps[0];
-        for (int i = 1; i <= m; i++) s = d_muladd<FUSED>(src[max(x - i, 0)] + src[min(x + i, Pw - 1)], taps[i], s);
+        for (int i = 1; i <= m; i++) s = d_muladd<FUSED>(src[max(x - i, 0)] + src[min(x + i, Pw - 1)], MA_TAP(taps, i), s);
         hsum[ch] = s;
     }
     double g11 = hsum[0], g12 = hsum[1], g22 = hsum[2], h1 = hsum[3], h2 = hsum[4];
@@ -503,7 +572,13 @@ void make_window_taps(int winsize, std::vector<float>& k)
     for (int i = 0; i <= m; i++) k[i] = (float)(k[i] * s);
 }
 
-constexpr int BV_R = 16, BV_NW = 4;   // fb_blur_v: 64 columns x 64 rows per block
+#ifndef MA_BV_NW
+#define MA_BV_NW 4
+#endif
+#ifndef MA_BV_R
+#define MA_BV_R 16
+#endif
+constexpr int BV_R = MA_BV_R, BV_NW = MA_BV_NW;   // fb_blur_v: 64 columns x (NW*R) rows per block
 constexpr int BH_R = 8, BH_NW = 8;    // fb_blur_h_solve: 64 rows x 64 columns per block
 constexpr size_t LDS_MAX = 160 * 1024;
 
@@ -519,8 +594,8 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
         dim3 grid((Pw + K1_TX - 1) / K1_TX, (Ph + K1_TY - 1) / K1_TY, nwin);
         hipLaunchKernelGGL((fb_polyexp_m0<T>), grid, dim3(K1_THREADS), 0, ctx->stream, prev, next, g, pc, ws);
     }
-    const size_t lds_v = (size_t)(BV_NW * BV_R + 2 * m) * 64 * sizeof(float);
-    const int colsh = BH_NW * BH_R + 2 * m;
+    const size_t lds_v = (size_t)(BV_NW * BV_R + 2 * m + 4) * 64 * sizeof(float);
+    const int colsh = BH_NW * BH_R + 2 * m + 4;
     size_t lds_h = (size_t)64 * (colsh | 1) * sizeof(float);
     const size_t lds_t = (size_t)5 * 32 * (BH_NW * BH_R + 1) * sizeof(float);
     if (lds_t > lds_h) lds_h = lds_t;
@@ -530,15 +605,15 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
         if (fast) {
             {
                 MaProfScope ps(ctx, MA_K_BLUR_V, px);
-                dim3 grid((Pw + 63) / 64, (Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R), nwin * 5);
-                hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), grid, dim3(64 * BV_NW), lds_v, ctx->stream, g, m,
-                                   taps, ws);
+                const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * nwin * 5;
+                hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_v,
+                                   ctx->stream, g, m, taps, ws, nwin * 5);
             }
             {
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px);
-                dim3 grid((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R), (Ph + 63) / 64, nwin);
-                hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED>), grid, dim3(64 * BH_NW), lds_h, ctx->stream,
-                                   g, m, taps, ws, last, flow_out);
+                const long long items = (long long)((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R)) * ((Ph + 63) / 64) * nwin;
+                hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BH_NW),
+                                   lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin);
             }
         } else {
             {
@@ -562,7 +637,8 @@ int get_taps(ma_ctx* ctx, int winsize, const float** out)
 {
     std::vector<float> k;
     make_window_taps(winsize, k);
-    return ma_const_table(ctx, ((uint64_t)1 << 56) | (uint64_t)winsize, k.data(), k.size(), out);
+    std::vector<float> t = ma_layout_taps(k);
+    return ma_const_table(ctx, ((uint64_t)1 << 56) | (uint64_t)winsize, t.data(), t.size(), out);
 }
 
 int farneback_impl(ma_ctx* ctx, const void* prev, const void* next, int dtype, int H, int W, int tile, int overlap,

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/microaligner_hip.h"
@@ -107,44 +108,165 @@ __device__ __forceinline__ float d_muladd(float a, float b, float c)
     return __fadd_rn(__fmul_rn(a, b), c);
 }
 
+// Device layout of a symmetric tap table k[0..m]: t[0] = k0, t[8 + (i-1)] = k_i for i >= 1, so that every group of
+// 4 or 8 consecutive taps starting at i = 1 (mod 8) is 16/32-byte aligned and loads with one s_load_dwordx4/x8.
+#define MA_TAP(t, i) ((t)[7 + (i)])
+static inline std::vector<float> ma_layout_taps(const std::vector<float>& k)
+{
+    std::vector<float> t(8 + (k.size() > 0 ? k.size() - 1 : 0) + 8, 0.f);
+    t[0] = k[0];
+    for (size_t i = 1; i < k.size(); i++) t[7 + i] = k[i];
+    return t;
+}
+
 // Symmetric FIR along one axis with a rotating register window (used by the Farneback window blur and the DOG
 // column pass).  `col` points at this thread's line in LDS, element j is col[j * stride].  For R consecutive
 // outputs starting at element jb:   s = c * k0;   s = (x[+i] + x[-i]) * k_i + s   for i = 1..m   (ascending i).
 // Full groups of R taps rotate the +i / -i windows through statically indexed registers (two LDS reads per
-// tap); the remaining m % R taps are read straight from LDS.  `last` is the largest valid element index.
+// tap); the remaining m % R taps are read straight from LDS.  The caller guarantees that elements
+// [jb - m - 2, jb + R + m + 1] are addressable (two guard elements beyond the halo on either side; their
+// values are loaded into the rotating windows but never used).
 template <int R, bool FUSED>
 __device__ __forceinline__ void d_sym_fir_slide(const float* __restrict__ col, const int stride, const int jb,
-                                                const int m, const int last, const float* __restrict__ taps,
-                                                float acc[R])
+                                                const int m, const float* __restrict__ taps, float acc[R])
 {
     float P[R], Q[R];
     const float k0 = taps[0];
 #pragma unroll
     for (int r = 0; r < R; r++) acc[r] = col[(jb + r) * stride] * k0;
 #pragma unroll
-    for (int o = 1; o <= R; o++) P[o % R] = col[min(jb + o, last) * stride];
+    for (int o = 1; o <= R; o++) P[o % R] = col[(jb + o) * stride];
 #pragma unroll
-    for (int o = -1; o <= R - 2; o++) Q[(o + R) % R] = col[max(jb + o, 0) * stride];
+    for (int o = -1; o <= R - 2; o++) Q[(o + R) % R] = col[(jb + o) * stride];
     const int full = m / R;
     for (int g = 0; g < full; g++) {
 #pragma unroll
         for (int ii = 0; ii < R; ii++) {
             const int i = g * R + ii + 1;
-            const float ki = taps[i];
+            const float ki = MA_TAP(taps, i);
 #pragma unroll
             for (int r = 0; r < R; r++)
                 acc[r] = d_muladd<FUSED>(P[(r + ii + 1) % R] + Q[((r - ii - 1) % R + R) % R], ki, acc[r]);
-            P[(ii + 1) % R] = col[min(jb + i + R, last) * stride];
-            Q[((-ii - 2) % R + R) % R] = col[max(jb - i - 1, 0) * stride];
+            P[(ii + 1) % R] = col[(jb + i + R) * stride];
+            Q[((-ii - 2) % R + R) % R] = col[(jb - i - 1) * stride];
         }
     }
     for (int i = full * R + 1; i <= m; i++) {
-        const float ki = taps[i];
+        const float ki = MA_TAP(taps, i);
 #pragma unroll
         for (int r = 0; r < R; r++)
             acc[r] = d_muladd<FUSED>(col[(jb + r + i) * stride] + col[(jb + r - i) * stride], ki, acc[r]);
     }
 }
+
+// Packed-math form of d_sym_fir_slide: v_pk_add_f32 / v_pk_mul_f32 (or v_pk_fma_f32) work on register pairs
+// and issue at ~1.2x the cost of a scalar op for twice the work on gfx950 (profiles/r01_ubench_valu.txt).
+// Outputs are paired H = R/2 apart: pair r = (out[r], out[r+H]).  At tap i it needs the input pairs
+// (x[r+i], x[r+H+i]) and (x[r-i], x[r+H-i]); with windows of pairs W[o] = (x[o], x[o+H]) both are W[r+i] and
+// W[r-i], so ONE alignment class suffices: the +i window holds o in [i, i+H-1], the -i window o in [-i, H-1-i],
+// each rotates one slot per tap through statically indexed registers (period H taps) and loads one new pair per
+// tap.  3R registers, like the scalar form.  Per component the operations and their order are exactly those of
+// the scalar form: results are bit-identical.
+// The pair loads are ds_read2(st64)_b32 written as inline asm: left to itself the compiler re-pairs the LDS reads
+// by adjacency and rebuilds the H-apart pairs with ~10 v_mov per tap.  Each tap issues its two loads first and
+// waits for them (s_waitcnt lgkmcnt(0), tied to the loaded registers) after its arithmetic.
+// ST64 = true : element stride is 64 floats (column of a [rows][64] LDS tile)  -> ds_read2st64_b32
+// ST64 = false: element stride is 1 float  (row of an LDS tile)                 -> ds_read2_b32
+// Addressable range required from the caller: [jb - m - 1, jb + R + m].
+typedef float ma_f2 __attribute__((ext_vector_type(2)));
+
+template <bool ST64, int O0, int O1>
+__device__ __forceinline__ ma_f2 d_lds_read_pair(unsigned addr)
+{
+    static_assert(O0 >= 0 && O0 < 256 && O1 >= 0 && O1 < 256, "ds_read2 offsets are 8 bit");
+    ma_f2 v;
+    if (ST64) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+    else asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1));
+    return v;
+}
+
+template <int H, bool FUSED, bool ST64, int II>
+__device__ __forceinline__ void d_fir_tap_pk(ma_f2 (&A)[H], ma_f2 (&P)[H], ma_f2 (&Q)[H], const float ki,
+                                             const unsigned addrP, const unsigned addrQ)
+{
+    // group-relative element offsets: +window entry o = i + H, i = g*H + II + 1 (addrP points at jb + g*H);
+    // -window entry o = -i - 1 (addrQ points at jb - g*H - H - 1)
+    ma_f2 pn = d_lds_read_pair<ST64, II + 1 + H, II + 1 + 2 * H>(addrP);
+    ma_f2 qn = d_lds_read_pair<ST64, H - 1 - II, 2 * H - 1 - II>(addrQ);
+    const ma_f2 kk = {ki, ki};
+    ma_f2 t[H];
+#pragma unroll
+    for (int r = 0; r < H; r++) t[r] = P[(r + II + 1) % H] + Q[((r - II - 1) % H + H) % H];
+    if (FUSED) {
+#pragma unroll
+        for (int r = 0; r < H; r++) A[r] = __builtin_elementwise_fma(t[r], kk, A[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < H; r++) t[r] = t[r] * kk;
+#pragma unroll
+        for (int r = 0; r < H; r++) A[r] = t[r] + A[r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pn), "+v"(qn));
+    P[(II + 1) % H] = pn;                  // o = i leaves, o = i + H enters
+    Q[((-II - 2) % H + H) % H] = qn;       // o = H-1-i leaves, o = -i-1 enters
+}
+
+template <int H, bool FUSED, bool ST64, int... II>
+__device__ __forceinline__ void d_fir_group_pk(ma_f2 (&A)[H], ma_f2 (&P)[H], ma_f2 (&Q)[H], const float* __restrict__ k,
+                                               const unsigned addrP, const unsigned addrQ,
+                                               std::integer_sequence<int, II...>)
+{
+    (d_fir_tap_pk<H, FUSED, ST64, II>(A, P, Q, k[II], addrP, addrQ), ...);
+}
+
+template <int R, bool FUSED, bool ST64>
+__device__ __forceinline__ void d_sym_fir_slide_pk(const float* __restrict__ col, const int jb, const int m,
+                                                   const float* __restrict__ taps, float acc[R])
+{
+    static_assert(R % 2 == 0, "R must be even");
+    constexpr int H = R / 2;
+    constexpr int stride = ST64 ? 64 : 1;
+    auto W2 = [&](int o) { return (ma_f2){col[(jb + o) * stride], col[(jb + o + H) * stride]}; };
+    ma_f2 A[H], P[H], Q[H];
+    const float k0 = taps[0];
+#pragma unroll
+    for (int r = 0; r < H; r++) A[r] = W2(r) * (ma_f2){k0, k0};
+#pragma unroll
+    for (int o = 1; o <= H; o++) P[o % H] = W2(o);               // tap 1: o in [1, H]
+#pragma unroll
+    for (int o = -1; o <= H - 2; o++) Q[(o + H) % H] = W2(o);    // tap 1: o in [-1, H-2]
+    const int full = m / H;
+    // LDS byte addresses (low 32 bits of a flat shared pointer are the LDS offset)
+    unsigned addrP = (unsigned)(size_t)(col + jb * stride);
+    unsigned addrQ = (unsigned)(size_t)(col + (jb - H - 1) * stride);
+    for (int g = 0; g < full; g++) {
+        float kg[H];  // this group's taps: one aligned scalar load
+#pragma unroll
+        for (int j = 0; j < H; j++) kg[j] = MA_TAP(taps, g * H + 1 + j);
+        d_fir_group_pk<H, FUSED, ST64>(A, P, Q, kg, addrP, addrQ, std::make_integer_sequence<int, H>{});
+        addrP += H * stride * 4;
+        addrQ -= H * stride * 4;
+    }
+#pragma unroll
+    for (int r = 0; r < H; r++) { acc[r] = A[r].x; acc[r + H] = A[r].y; }
+    for (int i = full * H + 1; i <= m; i++) {
+        const float ki = MA_TAP(taps, i);
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            acc[r] = d_muladd<FUSED>(col[(jb + r + i) * stride] + col[(jb + r - i) * stride], ki, acc[r]);
+    }
+}
+
+// XCD-aware work mapping (speed only, never correctness).  Workgroups of a 1-D grid are dealt round-robin to the
+// 8 XCDs (block b -> XCD b % 8), each with its own 4 MiB L2.  Stencil blocks that share a halo should therefore
+// be consecutive *within one XCD*: block b takes work item (b % 8) * ceil(N/8) + b / 8, so every XCD walks a
+// contiguous range of the work list in dispatch order.  Launch ma_xcd_grid(N) blocks; items >= N are skipped.
+__device__ __forceinline__ int d_xcd_work_item(int b, int n_items)
+{
+    const int per = (n_items + 7) >> 3;
+    return (b & 7) * per + (b >> 3);
+}
+static inline unsigned ma_xcd_grid(long long n_items) { return (unsigned)(((n_items + 7) / 8) * 8); }
 
 // Tile geometry shared by the tiled kernels (slicer.py / stitcher.py semantics).
 struct MaTiling {
