@@ -112,9 +112,8 @@ int minmax_host(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn, d
 constexpr int DR = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h, int w, int ksize,
-                                                const DogScalars* __restrict__ sc, const float* __restrict__ klo,
-                                                const float* __restrict__ khi, float* __restrict__ tlo,
-                                                float* __restrict__ thi)
+                                                const DogScalars* __restrict__ sc, const float* __restrict__ klh,
+                                                float* __restrict__ tlo, float* __restrict__ thi)
 {
     extern __shared__ float lds[];  // [DR][256 + 2r]
     const int r = ksize / 2, span = 256 + 2 * r;
@@ -131,19 +130,22 @@ __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h
     __syncthreads();
     const int x = x0 + threadIdx.x;
     if (x >= w) return;
+    // both sigmas as one register pair: klh[j] = (k_lo[j], k_hi[j]); acc = acc + k * v per component, left to right
+    const ma_f2* __restrict__ kk = reinterpret_cast<const ma_f2*>(klh);
 #pragma unroll
     for (int row = 0; row < DR; row++) {
         const int y = y0 + row;
         if (y >= h) break;
         const float* v = lds + row * span + threadIdx.x;
-        float accl = klo[0] * v[0], acch = khi[0] * v[0];
+        ma_f2 acc = kk[0] * (ma_f2){v[0], v[0]};
+#pragma unroll 8
         for (int j = 1; j < ksize; j++) {
-            float vj = v[j];
-            accl = accl + klo[j] * vj;
-            acch = acch + khi[j] * vj;
+            const float vj = v[j];
+            const ma_f2 p = kk[j] * (ma_f2){vj, vj};
+            acc = acc + p;
         }
-        tlo[(size_t)y * w + x] = accl;
-        thi[(size_t)y * w + x] = acch;
+        tlo[(size_t)y * w + x] = acc.x;
+        thi[(size_t)y * w + x] = acc.y;
     }
 }
 
@@ -170,9 +172,17 @@ __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict
     float sl[R], sh[R];
     for (int arr = 0; arr < 2; arr++) {
         const float* src = arr == 0 ? tlo : thi;
-        for (int j = wv; j < rows; j += NW) {
-            int y = d_reflect101(y0 - r - G + j, h);
-            lds[j * 64 + lane] = src[(size_t)y * w + xc];
+        {
+            constexpr int SB = 16;  // global loads issued per wave before the first LDS store
+            const float* scol = src + xc;
+            for (int j0 = wv; j0 < rows; j0 += NW * SB) {
+                float v[SB];
+#pragma unroll
+                for (int k = 0; k < SB; k++) v[k] = scol[(size_t)d_reflect101(y0 - r - G + min(j0 + NW * k, rows - 1), h) * w];
+#pragma unroll
+                for (int k = 0; k < SB; k++)
+                    if (j0 + NW * k < rows) lds[(j0 + NW * k) * 64 + lane] = v[k];
+            }
         }
         __syncthreads();
         if (arr == 0) d_sym_fir_slide_pk<R, false, true>(lds + lane, G + r + wv * R, r, klo_c, sl);
@@ -256,7 +266,7 @@ void gaussian_kernel(int ksize, double sigma, std::vector<float>& k)
 
 int grid_for(size_t n) { size_t b = (n + 256 * 4 - 1) / (256 * 4); return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
-constexpr int DC_R = 16, DC_NW = 4;
+constexpr int DC_NW = 4;  // column pass: 64 columns x 4*R rows per block; R = 20 when r % 10 == 0 (no tail taps) else 16
 
 } // namespace
 
@@ -283,16 +293,19 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     const int ksize = low_sigma * 4 * 2 + 1;  // optflow_registrator.py:262
     const int r = ksize / 2;
     const size_t lds_rows = (size_t)DR * (256 + 2 * r) * sizeof(float);
+    const int DC_R = (r % 10 == 0) ? 20 : 16;
     const size_t lds_cols = (size_t)(DC_NW * DC_R + 2 * r + 4) * 64 * sizeof(float);
     MA_REQUIRE(lds_rows <= 160 * 1024 && lds_cols <= 160 * 1024, "low_sigma too large for the LDS-staged DOG kernels");
 
     std::vector<float> klo, khi;
     gaussian_kernel(ksize, low_sigma, klo);
     gaussian_kernel(ksize, high_sigma, khi);
-    const float *dlo = nullptr, *dhi = nullptr, *dloc = nullptr, *dhic = nullptr;
+    const float *dlo = nullptr, *dloc = nullptr, *dhic = nullptr;
     const uint64_t key = ((uint64_t)ksize << 16);
-    MA_TRY(ma_const_table(ctx, ((uint64_t)2 << 56) | key | (uint64_t)low_sigma, klo.data(), klo.size(), &dlo));
-    MA_TRY(ma_const_table(ctx, ((uint64_t)2 << 56) | key | (uint64_t)high_sigma, khi.data(), khi.size(), &dhi));
+    std::vector<float> klh(2 * (size_t)ksize);  // row pass: (lo, hi) interleaved
+    for (int j = 0; j < ksize; j++) { klh[2 * j] = klo[j]; klh[2 * j + 1] = khi[j]; }
+    MA_TRY(ma_const_table(ctx, ((uint64_t)2 << 56) | key | ((uint64_t)low_sigma << 8) | (uint64_t)high_sigma, klh.data(),
+                          klh.size(), &dlo));
     // centre-first halves for the symmetric column pass: c[i] = k[r + i]
     std::vector<float> clo = ma_layout_taps(std::vector<float>(klo.begin() + r, klo.end()));
     std::vector<float> chi = ma_layout_taps(std::vector<float>(khi.begin() + r, khi.end()));
@@ -317,12 +330,16 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc);
     {
         dim3 grid((w + 255) / 256, (h + DR - 1) / DR), block(256);
-        if (dtype == MA_U8) hipLaunchKernelGGL((dog_rows<uint8_t>), grid, block, lds_rows, ctx->stream, (const uint8_t*)src, h, w, ksize, sc, dlo, dhi, tlo, thi);
-        else if (dtype == MA_U16) hipLaunchKernelGGL((dog_rows<uint16_t>), grid, block, lds_rows, ctx->stream, (const uint16_t*)src, h, w, ksize, sc, dlo, dhi, tlo, thi);
-        else hipLaunchKernelGGL((dog_rows<float>), grid, block, lds_rows, ctx->stream, (const float*)src, h, w, ksize, sc, dlo, dhi, tlo, thi);
+        if (dtype == MA_U8) hipLaunchKernelGGL((dog_rows<uint8_t>), grid, block, lds_rows, ctx->stream, (const uint8_t*)src, h, w, ksize, sc, dlo, tlo, thi);
+        else if (dtype == MA_U16) hipLaunchKernelGGL((dog_rows<uint16_t>), grid, block, lds_rows, ctx->stream, (const uint16_t*)src, h, w, ksize, sc, dlo, tlo, thi);
+        else hipLaunchKernelGGL((dog_rows<float>), grid, block, lds_rows, ctx->stream, (const float*)src, h, w, ksize, sc, dlo, tlo, thi);
     }
-    hipLaunchKernelGGL((dog_cols_diff<DC_R, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
-                       ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
+    if (DC_R == 20)
+        hipLaunchKernelGGL((dog_cols_diff<20, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
+                           ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
+    else
+        hipLaunchKernelGGL((dog_cols_diff<16, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
+                           ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
     hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, ctx->stream, part, (int)nblk, sc->mm_diff);
     hipLaunchKernelGGL(dog_params_out, dim3(1), dim3(1), 0, ctx->stream, sc);
     hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst);

@@ -1,0 +1,45 @@
+"""The N > 1 path on CPU: two processes, gloo, 127.0.0.1 (no GPU needed)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from microaligner_amd import parallel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_is_a_partition():
+    for n in (0, 1, 5, 8, 17):
+        for ws in (1, 2, 3, 8):
+            parts = [parallel.shard(n, r, ws) for r in range(ws)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    with pytest.raises(ValueError):
+        parallel.shard(4, 2, 2)
+
+
+def test_single_process_run_sharded():
+    assert parallel.run_sharded([1, 2, 3], lambda v: v * v) == [1, 4, 9]
+    assert parallel.run_sharded([1, 2, 3], lambda v: v * v, gather=False) == {0: 1, 1: 4, 2: 9}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_gloo(tmp_path):
+    out = tmp_path / "result.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"), str(out)]
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(out))
+    assert res == {"ok": True, "world": 2, "units": 5}
