@@ -159,7 +159,8 @@ __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict
                                                          float* __restrict__ part)
 {
     extern __shared__ float lds[];  // [(NW*R + 2r)][64]
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = ksize / 2;
     // y-fastest work list walked contiguously per XCD (d_xcd_work_item): halo rows come from the XCD's L2
     const int nbx = (w + 63) / 64, nby = (h + NW * R - 1) / (NW * R);

@@ -202,12 +202,16 @@ __global__ __launch_bounds__(K1_THREADS) void fb_polyexp_m0(const T* __restrict_
 // Lanes run along x; each thread owns one column and R consecutive output rows, sliding a register
 // window over an LDS-staged column strip:  s = c*k0;  s = (dn_i + up_i)*k_i + s  for i = 1..m.
 // ---------------------------------------------------------------------------------------------
+#ifndef MA_BV_WAVES
+#define MA_BV_WAVES 6
+#endif
 template <int R, int NW, bool FUSED>
-__global__ __launch_bounds__(64 * NW) void fb_blur_v(FbGeom g, int m, const float* __restrict__ taps,
+__global__ __launch_bounds__(64 * NW, MA_BV_WAVES) void fb_blur_v(FbGeom g, int m, const float* __restrict__ taps,
                                                      float* __restrict__ ws, int nplanes)
 {
     extern __shared__ float lds[];  // [(NW*R + 2m)][64]
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index: keeps row math on the SALU
     const int Ph = g.t.Ph, Pw = g.t.Pw;
     // work list ordered y-fastest inside a column strip, walked contiguously per XCD: the 2m halo rows that
     // vertically adjacent blocks share are then served by that XCD's L2 instead of being re-fetched
@@ -269,7 +273,11 @@ __global__ __launch_bounds__(64 * NW) void fb_blur_v(FbGeom g, int m, const floa
 #ifndef MA_BH_WAVES
 #define MA_BH_WAVES 6
 #endif
-template <int R, int NW, bool FUSED>
+#ifndef MA_BH_PREFETCH
+#define MA_BH_PREFETCH 0
+#endif
+// Q = ceil((NW*R + 2m + 4) / 64): column chunks of the staged row tile
+template <int R, int NW, bool FUSED, int Q>
 __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g, int m, const float* __restrict__ taps,
                                                            float* __restrict__ ws, int last,
                                                            float* __restrict__ flow_out, int nwin)
@@ -278,7 +286,8 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
     constexpr int TXW = NW * R;           // output columns per block
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index: keeps row/column math on the SALU
     const int Ph = g.t.Ph, Pw = g.t.Pw;
     // x-fastest work list walked contiguously per XCD (see fb_blur_v): horizontally adjacent blocks share 2m columns
     const int nbx = (Pw + TXW - 1) / TXW, nby = (Ph + 63) / 64;
@@ -291,47 +300,48 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
     const int cols = TXW + 2 * m + 2 * G;
     const int lp = cols | 1;              // odd LDS pitch: lanes (rows) hit distinct banks
 
+    // Staging of one plane: 64/NW rows x Q column chunks per wave; every global load is issued before the first
+    // LDS store, and the loads of plane ch+1 are issued before plane ch is filtered (register prefetch), so their
+    // latency hides behind the FIR.
+    constexpr int RW = 64 / NW;
+    float v[RW][Q];
+    int xi[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) xi[q] = d_clamp(x0 - m - G + lane + 64 * q, 0, Pw - 1);
+    auto issue = [&](int ch) {
+        const float* src = plane_ptr(ws, g, wl, PL_V + ch);
+#pragma unroll
+        for (int k = 0; k < RW; k++) {
+            const float* srow = src + (size_t)min(y0 + w + NW * k, Ph - 1) * g.pitch;
+#pragma unroll
+            for (int q = 0; q < Q; q++) v[k][q] = srow[xi[q]];
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < RW; k++)
+#pragma unroll
+            for (int q = 0; q < Q; q++)
+                if (lane + 64 * q < cols) lds[(w + NW * k) * lp + lane + 64 * q] = v[k][q];
+    };
+
     float hs[5][R];
+    issue(0);
 #pragma unroll
     for (int ch = 0; ch < 5; ch++) {
-        const float* src = plane_ptr(ws, g, wl, PL_V + ch);
-        // stage rows y0..y0+63, columns x0-m .. x0+TXW+m-1 (replicate), coalesced along x
-#ifndef MA_ABL_NOSTAGE
-        if (cols <= 192) {
-            // 64/NW rows x 3 column chunks per wave, every load issued before the first LDS store
-            constexpr int RW = 64 / NW;
-            float v[RW][3];
-            int xi[3];
-#pragma unroll
-            for (int q = 0; q < 3; q++) xi[q] = d_clamp(x0 - m - G + lane + 64 * q, 0, Pw - 1);
-#pragma unroll
-            for (int k = 0; k < RW; k++) {
-                const float* srow = src + (size_t)min(y0 + w + NW * k, Ph - 1) * g.pitch;
-#pragma unroll
-                for (int q = 0; q < 3; q++) v[k][q] = srow[xi[q]];
-            }
-#pragma unroll
-            for (int k = 0; k < RW; k++)
-#pragma unroll
-                for (int q = 0; q < 3; q++)
-                    if (lane + 64 * q < cols) lds[(w + NW * k) * lp + lane + 64 * q] = v[k][q];
-        } else {
-            for (int j = w; j < 64; j += NW) {
-                const float* srow = src + (size_t)min(y0 + j, Ph - 1) * g.pitch;
-                for (int c = lane; c < cols; c += 64) lds[j * lp + c] = srow[d_clamp(x0 - m - G + c, 0, Pw - 1)];
-            }
-        }
-#endif
+        commit();
         __syncthreads();
-        float acc[R];
-#ifndef MA_ABL_NOFIR
-        d_sym_fir_slide_pk<R, FUSED, false>(lds + lane * lp, G + m + w * R, m, taps, acc);
-#else
-        for (int r = 0; r < R; r++) acc[r] = lds[lane * lp + G + m + w * R + r];
+#if MA_BH_PREFETCH
+        if (ch < 4) issue(ch + 1);
 #endif
+        float acc[R];
+        d_sym_fir_slide_pk<R, FUSED, false>(lds + lane * lp, G + m + w * R, m, taps, acc);
 #pragma unroll
         for (int r = 0; r < R; r++) hs[ch][r] = acc[r];
         __syncthreads();
+#if !MA_BH_PREFETCH
+        if (ch < 4) issue(ch + 1);
+#endif
     }
 
     // transpose through LDS in two halves of 32 rows: tb[ch][32][TXW+1]
@@ -599,7 +609,7 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
     size_t lds_h = (size_t)64 * (colsh | 1) * sizeof(float);
     const size_t lds_t = (size_t)5 * 32 * (BH_NW * BH_R + 1) * sizeof(float);
     if (lds_t > lds_h) lds_h = lds_t;
-    const bool fast = m >= 1 && lds_v <= LDS_MAX && lds_h <= LDS_MAX;
+    const bool fast = m >= 1 && lds_v <= LDS_MAX && lds_h <= LDS_MAX && colsh <= 320;  // 320 = 5 chunks (winsize <= 253)
     for (int it = 0; it < iters; it++) {
         const int last = it == iters - 1;
         if (fast) {
@@ -612,8 +622,12 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
             {
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px);
                 const long long items = (long long)((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R)) * ((Ph + 63) / 64) * nwin;
-                hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BH_NW),
-                                   lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin);
+                if (colsh <= 192)
+                    hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 3>), dim3(ma_xcd_grid(items)),
+                                       dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin);
+                else
+                    hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 5>), dim3(ma_xcd_grid(items)),
+                                       dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin);
             }
         } else {
             {

@@ -78,16 +78,18 @@ __global__ __launch_bounds__(256) void nmi_reduce_kernel(const unsigned* __restr
     const size_t c0 = (size_t)blockIdx.x * chunk;
     const double N = (double)((c0 + chunk < n ? c0 + chunk : n) - c0);
 
-    pa[j] = 0;
     if (j < 2) cnt[j] = 0;
-    __syncthreads();
+    // marginals: thread j sums column j (coalesced across the wave) and row j (64 independent 16-byte loads);
+    // all loads are independent, nothing is reduced across lanes
     unsigned long long pbj = 0;
-    for (int r = 0; r < 256; r++) {
-        unsigned v = hh[r * 256 + j];
-        pbj += v;
-        unsigned s = v;
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
-        if (lane == 0) atomicAdd(&pa[r], s);
+#pragma unroll 16
+    for (int r = 0; r < 256; r++) pbj += hh[r * 256 + j];
+    {
+        const uint4* row = reinterpret_cast<const uint4*>(hh + j * 256);
+        unsigned s = 0;
+#pragma unroll 16
+        for (int q = 0; q < 64; q++) { uint4 v = row[q]; s += v.x + v.y + v.z + v.w; }
+        pa[j] = s;
     }
     pb_s[j] = pbj;
     __syncthreads();
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(256) void nmi_reduce_kernel(const unsigned* __restr
     const double logN = log(N);
     double mi = 0.0;
     if (pbj > 0) {
+#pragma unroll 8
         for (int r = 0; r < 256; r++) {
             unsigned nij = hh[r * 256 + j];
             if (nij) {
