@@ -190,13 +190,22 @@ __device__ __forceinline__ void d_fir_tap_pk(ma_f2 (&A)[H], ma_f2 (&P)[H], ma_f2
                                              const unsigned addrP, const unsigned addrQ)
 {
     // group-relative element offsets: +window entry o = i + H, i = g*H + II + 1 (addrP points at jb + g*H);
-    // -window entry o = -i - 1 (addrQ points at jb - g*H - H - 1)
-    ma_f2 pn = d_lds_read_pair<ST64, II + 1 + H, II + 1 + 2 * H>(addrP);
-    ma_f2 qn = d_lds_read_pair<ST64, H - 1 - II, 2 * H - 1 - II>(addrQ);
+    // -window entry o = -i - 1 (addrQ points at jb - g*H - H - 1).
+    // The outgoing +pair (slot SP) is read only by output pair 0 and the outgoing -pair (slot SQ) only by output
+    // pair H-1: those two sums go first, then the new pairs are loaded INTO THE SAME registers, so the windows
+    // never change registers across the loop back-edge (otherwise: 4 v_mov per tap).
+    constexpr int SP = (II + 1) % H, SQ = ((-II - 2) % H + H) % H;
+    static_assert(((H - 1 - II - 1) % H + H) % H == SQ, "slot bookkeeping");
     const ma_f2 kk = {ki, ki};
     ma_f2 t[H];
+    t[0] = P[SP] + Q[((0 - II - 1) % H + H) % H];
+    if (H > 1) t[H - 1] = P[(H - 1 + II + 1) % H] + Q[SQ];
+    __builtin_amdgcn_sched_barrier(0);
+    P[SP] = d_lds_read_pair<ST64, II + 1 + H, II + 1 + 2 * H>(addrP);
+    Q[SQ] = d_lds_read_pair<ST64, H - 1 - II, 2 * H - 1 - II>(addrQ);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 0; r < H; r++) t[r] = P[(r + II + 1) % H] + Q[((r - II - 1) % H + H) % H];
+    for (int r = 1; r < H - 1; r++) t[r] = P[(r + II + 1) % H] + Q[((r - II - 1) % H + H) % H];
     if (FUSED) {
 #pragma unroll
         for (int r = 0; r < H; r++) A[r] = __builtin_elementwise_fma(t[r], kk, A[r]);
@@ -206,9 +215,7 @@ __device__ __forceinline__ void d_fir_tap_pk(ma_f2 (&A)[H], ma_f2 (&P)[H], ma_f2
 #pragma unroll
         for (int r = 0; r < H; r++) A[r] = t[r] + A[r];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pn), "+v"(qn));
-    P[(II + 1) % H] = pn;                  // o = i leaves, o = i + H enters
-    Q[((-II - 2) % H + H) % H] = qn;       // o = H-1-i leaves, o = -i-1 enters
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(P[SP]), "+v"(Q[SQ]));
 }
 
 template <int H, bool FUSED, bool ST64, int... II>
