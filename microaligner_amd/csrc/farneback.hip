@@ -234,12 +234,12 @@ __global__ __launch_bounds__(64 * NW, MA_BV_WAVES) void fb_blur_v(FbGeom g, int 
 #define MA_BV_SB 42
 #endif
         constexpr int SB = MA_BV_SB;
-        const float* scol = src + xc;
+        const unsigned xo = (unsigned)xc * 4u;  // row base is wave-uniform (SGPR), the lane byte offset is 32 bit
         for (int j0 = w; j0 < rows; j0 += NW * SB) {
             float v[SB];
 #pragma unroll
             for (int k = 0; k < SB; k++)
-                v[k] = scol[(size_t)d_clamp(y0 - m - G + j0 + NW * k, 0, Ph - 1) * g.pitch];
+                v[k] = d_ldg(src + (size_t)d_clamp(y0 - m - G + j0 + NW * k, 0, Ph - 1) * g.pitch, xo);
 #pragma unroll
             for (int k = 0; k < SB; k++)
                 if (j0 + NW * k < rows) lds[(j0 + NW * k) * 64 + lane] = v[k];
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(64 * NW, MA_BV_WAVES) void fb_blur_v(FbGeom g, int 
     if (x < Pw) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            int y = y0 + w * R + r;
-            if (y < Ph) dst[(size_t)y * g.pitch + x] = acc[r];
+            const int y = y0 + w * R + r;
+            if (y < Ph) d_stg(dst + (size_t)y * g.pitch, (unsigned)x * 4u, acc[r]);
         }
     }
 }
@@ -389,10 +389,11 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
                     }
                 } else {
                     // UpdateMatrices (A.1 step 3) at this pixel
-                    const size_t pix = (size_t)y * g.pitch + x;
+                    const unsigned plane = (unsigned)g.plane;
+                    const unsigned pix = (unsigned)y * (unsigned)g.pitch + (unsigned)x;
                     float r0[5];
 #pragma unroll
-                    for (int k = 0; k < 5; k++) r0[k] = R0p[k * g.plane + pix];
+                    for (int k = 0; k < 5; k++) r0[k] = R0p[k * plane + pix];
                     float fx = (float)x + dx, fy = (float)y + dy;
                     int x1 = d_cvfloor(fx), y1 = d_cvfloor(fy);
                     fx -= (float)x1; fy -= (float)y1;
@@ -401,17 +402,17 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
                     if (inside) {
                         float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy,
                               a11 = fx * fy;
-                        const float* q = R1p + (size_t)y1 * g.pitch + x1;
+                        const unsigned q0 = (unsigned)y1 * (unsigned)g.pitch + (unsigned)x1, q1 = q0 + (unsigned)g.pitch;
 #pragma unroll
                         for (int k = 0; k < 5; k++) {
-                            const float* qk = q + k * g.plane;
-                            r[k] = a00 * qk[0] + a01 * qk[1] + a10 * qk[g.pitch] + a11 * qk[g.pitch + 1];
+                            const float* qk = R1p + k * plane;
+                            r[k] = a00 * qk[q0] + a01 * qk[q0 + 1] + a10 * qk[q1] + a11 * qk[q1 + 1];
                         }
                     }
                     float Mv[5];
                     update_matrices_px(r0, r[0], r[1], r[2], r[3], r[4], inside, dx, dy, x, y, Pw, Ph, Mv);
 #pragma unroll
-                    for (int k = 0; k < 5; k++) Mp[k * g.plane + pix] = Mv[k];
+                    for (int k = 0; k < 5; k++) Mp[k * plane + pix] = Mv[k];
                 }
             }
         }

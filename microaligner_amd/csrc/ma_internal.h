@@ -100,6 +100,17 @@ __device__ __forceinline__ int d_cvfloor(float v)
 template <typename T>
 __device__ __forceinline__ float d_to_f32(T v) { return (float)v; }
 
+// Global access as wave-uniform base + 32-bit per-lane BYTE offset: lets the compiler pick the
+// `global_load_dword v, voffset, s[base:base+1]` form (no 64-bit VALU address arithmetic per access).
+__device__ __forceinline__ float d_ldg(const float* ubase, unsigned byte_off)
+{
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ubase) + byte_off);
+}
+__device__ __forceinline__ void d_stg(float* ubase, unsigned byte_off, float v)
+{
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(ubase) + byte_off) = v;
+}
+
 // multiply-add with selectable rounding model (see MA_FB_MULADD_FUSED)
 template <bool FUSED>
 __device__ __forceinline__ float d_muladd(float a, float b, float c)
