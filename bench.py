@@ -56,14 +56,29 @@ def algorithmic_bytes_per_px(kernel, iters, esz):
     return 0
 
 
-def roofline_entry(name, rec, iters, esz):
+def pmc_traffic(workload):
+    """HBM bytes per step and kernel group from the committed rocprofv3 PMC summary of this very command
+    (profiles/rNN_hbm_traffic_<workload>.json, tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the bench."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_{workload}.json")))
+    if not files:
+        return {}
+    return json.load(open(files[-1])).get("per_bench_group_bytes_per_step", {})
+
+
+def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None):
     if rec["launches"] == 0 or rec["ms"] <= 0:
         return None
     bpp = algorithmic_bytes_per_px(name, iters, esz)
     gbs = bpp * rec["px"] / (rec["ms"] * 1e-3) / 1e9
+    traffic = None
+    if traffic_per_step and name in traffic_per_step:
+        traffic = round(traffic_per_step[name] * steps / rec["launches"])  # HBM bytes per launch (PMC)
     return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
             "avg_launch_ms": round(rec["ms"] / rec["launches"], 4), "launches": rec["launches"],
+            "algorithmic_bytes_per_launch": round(bpp * rec["px"] / rec["launches"]),
             "algorithmic_bytes_per_px": round(bpp, 2), "px_per_launch": round(rec["px"] / rec["launches"])}
 
 
@@ -162,7 +177,9 @@ def main():
         iters, esz = reg.num_iterations, 4
         # with use_dog the Farneback inputs are the uint8 DOG images (1 B/px), not the f32 level images
         fb_esz = 1 if reg.use_dog else esz
-        kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz) for k, v in prof.items()}
+        tps = pmc_traffic(args.workload) if not args.size and not args.fused else {}
+        kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz, args.steps, tps)
+                   for k, v in prof.items()}
         kernels = {k: v for k, v in kernels.items() if v}
         total_kernel_ms = sum(v["ms"] for v in prof.values())
         dominant = max(kernels, key=lambda k: prof[k]["ms"]) if kernels else None

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for profiles/: kernel trace + stats, and HBM traffic counters in separate
+# --pmc passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass).  Run on the GPU box:
+#   bash tools/collect_profiles.sh r01
+set -e
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- $CMD > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
+rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- $CMD > /dev/null 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE -d $OUT/write --output-format csv -- $CMD > /dev/null 2> $OUT/write.err
+python3 tools/summarise_profiles.py $OUT $TAG
