@@ -25,6 +25,7 @@ struct FbGeom {
     int pitch;          // floats per plane row
     int tile0;          // global index of the first window of this batch
     size_t plane;       // floats per plane = Ph * pitch
+    int margin;         // active-extent margin (see window_extent); >= Ph, Pw disables the optimisation
 };
 
 struct PolyConsts {
@@ -54,6 +55,21 @@ __device__ __forceinline__ void window_origin(const MaTiling& t, int widx, int& 
     int ty = widx / t.ntx, tx = widx - ty * t.ntx;
     oy = ty * t.T - t.ov;
     ox = tx * t.T - t.ov;
+}
+
+// Active extent of a window.  Right/bottom border windows are mostly zero padding (slicer.py pads every window to
+// (tile+2*overlap)^2).  With vx = number of window columns that lie inside the image, the polynomial expansions
+// vanish for x >= vx + 2 and, by induction over the iterations (a matrix entry can only become non-zero where the
+// blurred previous field, hence the flow, is non-zero), M_k vanishes for x >= vx + 2 + k*m.  All fields are
+// therefore exactly +0 beyond  ex = vx + (iterations-1)*m + 3  (same along y), nothing outside [0,ex) x [0,ey)
+// can influence a pixel inside the image, and the kernels neither compute nor read there: loads beyond the
+// extent are replaced by 0.f, work items beyond it exit.  Bit-identical to processing the full window
+// (tests compare against the oracle, which does process it); saves 9 % (16384^2) to 31 % (4096^2) of the work.
+__device__ __forceinline__ void window_extent(const FbGeom& g, int oy, int ox, int& ey, int& ex)
+{
+    const int vy = min(g.t.Ph, g.t.H - oy), vx = min(g.t.Pw, g.t.W - ox);
+    ey = min(g.t.Ph, vy + min(g.margin, g.t.Ph));
+    ex = min(g.t.Pw, vx + min(g.margin, g.t.Pw));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -109,8 +125,10 @@ __global__ __launch_bounds__(K1_THREADS) void fb_polyexp_m0(const T* __restrict_
     const int x0 = blockIdx.x * K1_TX, y0 = blockIdx.y * K1_TY;
     const int wl = blockIdx.z;
     const int Ph = g.t.Ph, Pw = g.t.Pw;
-    int oy, ox;
+    int oy, ox, ey, ex;
     window_origin(g.t, g.tile0 + wl, oy, ox);
+    window_extent(g, oy, ox, ey, ex);
+    if (x0 >= ex || y0 >= ey) return;  // nothing but exact zeros there
 
     const int lx = tid & 63, lyg = tid >> 6;  // output mapping: column lx, rows lyg*4 .. lyg*4+3
     float r0v[4][5];
@@ -216,17 +234,27 @@ __global__ __launch_bounds__(64 * NW, MA_BV_WAVES) void fb_blur_v(FbGeom g, int 
     // work list ordered y-fastest inside a column strip, walked contiguously per XCD: the 2m halo rows that
     // vertically adjacent blocks share are then served by that XCD's L2 instead of being re-fetched
     const int nbx = (Pw + 63) / 64, nby = (Ph + NW * R - 1) / (NW * R);
-    const int item = d_xcd_work_item(blockIdx.x, nbx * nby * nplanes);
-    if (item >= nbx * nby * nplanes) return;
-    const int by = item % nby, bx = (item / nby) % nbx, bz = item / (nby * nbx);
+    // (window, plane) units interleaved over the XCDs (d_xcd_unit): border windows, which are mostly skipped
+    // (window_extent), are spread evenly.  Measured alternatives (profiles/r01_notes.md): contiguous unit ranges
+    // per XCD leave one XCD idle early; window-major interleaving is 25 % slower on this kernel.
+    const int nslots = (int)(((nplanes + 7) / 8) * 8);
+    const int item = d_xcd_work_item(blockIdx.x, nbx * nby * nslots);
+    const int by = item % nby, bx = (item / nby) % nbx;
+    const int bz = d_xcd_unit(item / (nby * nbx), nplanes);
+    if (bz >= nplanes) return;
     const int x0 = bx * 64, y0 = by * (NW * R);
     const int wl = bz / 5, ch = bz - wl * 5;
     const float* src = plane_ptr(ws, g, wl, PL_M + ch);
     float* dst = plane_ptr(ws, g, wl, PL_V + ch);
+    int oy, ox, ey, ex;
+    window_origin(g.t, g.tile0 + wl, oy, ox);
+    window_extent(g, oy, ox, ey, ex);
+    if (x0 >= ex || y0 >= ey) return;
 
     constexpr int G = 2;  // guard rows on either side (d_sym_fir_slide contract)
     const int rows = NW * R + 2 * m + 2 * G;
     const int xc = min(x0 + lane, Pw - 1);
+    const bool xin = xc < ex;
 #ifndef MA_ABL_NOSTAGE
     {
         // rows in batches of SB per wave: all SB global loads are issued before the first LDS store
@@ -238,8 +266,11 @@ __global__ __launch_bounds__(64 * NW, MA_BV_WAVES) void fb_blur_v(FbGeom g, int 
         for (int j0 = w; j0 < rows; j0 += NW * SB) {
             float v[SB];
 #pragma unroll
-            for (int k = 0; k < SB; k++)
-                v[k] = d_ldg(src + (size_t)d_clamp(y0 - m - G + j0 + NW * k, 0, Ph - 1) * g.pitch, xo);
+            for (int k = 0; k < SB; k++) {
+                const int y = d_clamp(y0 - m - G + j0 + NW * k, 0, Ph - 1);
+                v[k] = d_ldg(src + (size_t)min(y, ey - 1) * g.pitch, xo);
+                if (y >= ey || !xin) v[k] = 0.f;  // beyond the active extent M is exactly zero (and was not written)
+            }
 #pragma unroll
             for (int k = 0; k < SB; k++)
                 if (j0 + NW * k < rows) lds[(j0 + NW * k) * 64 + lane] = v[k];
@@ -291,11 +322,16 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
     const int Ph = g.t.Ph, Pw = g.t.Pw;
     // x-fastest work list walked contiguously per XCD (see fb_blur_v): horizontally adjacent blocks share 2m columns
     const int nbx = (Pw + TXW - 1) / TXW, nby = (Ph + 63) / 64;
-    const int item = d_xcd_work_item(blockIdx.x, nbx * nby * nwin);
-    if (item >= nbx * nby * nwin) return;
+    const int nslots = (int)(((nwin + 7) / 8) * 8);
+    const int item = d_xcd_work_item(blockIdx.x, nbx * nby * nslots);
     const int bx = item % nbx, by = (item / nbx) % nby;
     const int x0 = bx * TXW, y0 = by * 64;
-    const int wl = item / (nbx * nby);
+    const int wl = d_xcd_unit(item / (nbx * nby), nwin);  // windows interleaved over the XCDs (see fb_blur_v)
+    if (wl >= nwin) return;
+    int oy, ox, ey, ex;
+    window_origin(g.t, g.tile0 + wl, oy, ox);
+    window_extent(g, oy, ox, ey, ex);
+    if (x0 >= ex || y0 >= ey) return;
     constexpr int G = 2;  // guard columns on either side (d_sym_fir_slide contract)
     const int cols = TXW + 2 * m + 2 * G;
     const int lp = cols | 1;              // odd LDS pitch: lanes (rows) hit distinct banks
@@ -314,7 +350,10 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
         for (int k = 0; k < RW; k++) {
             const float* srow = src + (size_t)min(y0 + w + NW * k, Ph - 1) * g.pitch;
 #pragma unroll
-            for (int q = 0; q < Q; q++) v[k][q] = srow[xi[q]];
+            for (int q = 0; q < Q; q++) {
+                v[k][q] = srow[min(xi[q], ex - 1)];
+                if (xi[q] >= ex) v[k][q] = 0.f;  // V is exactly zero right of the active extent
+            }
         }
     };
     auto commit = [&]() {
@@ -346,8 +385,6 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
 
     // transpose through LDS in two halves of 32 rows: tb[ch][32][TXW+1]
     constexpr int TP = TXW + 1;
-    int oy, ox;
-    window_origin(g.t, g.tile0 + wl, oy, ox);
     const float* R0p = plane_ptr(ws, g, wl, PL_R0);
     const float* R1p = plane_ptr(ws, g, wl, PL_R1);
     float* Mp = plane_ptr(ws, g, wl, PL_M);
@@ -399,7 +436,9 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
                     fx -= (float)x1; fy -= (float)y1;
                     float r[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
                     const bool inside = (unsigned)x1 < (unsigned)(Pw - 1) && (unsigned)y1 < (unsigned)(Ph - 1);
-                    if (inside) {
+                    // R1 is exactly zero beyond the active extent (and was not written there)
+                    const bool r1zero = x1 + 1 >= ex || y1 + 1 >= ey;
+                    if (inside && !r1zero) {
                         float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy,
                               a11 = fx * fy;
                         const unsigned q0 = (unsigned)y1 * (unsigned)g.pitch + (unsigned)x1, q1 = q0 + (unsigned)g.pitch;
@@ -600,29 +639,35 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
     float* ws = (float*)ctx->ws;
     const int Ph = g.t.Ph, Pw = g.t.Pw;
     const double px = (double)nwin * Ph * Pw;
-    {
-        MaProfScope ps(ctx, MA_K_POLYEXP_M0, px);
-        dim3 grid((Pw + K1_TX - 1) / K1_TX, (Ph + K1_TY - 1) / K1_TY, nwin);
-        hipLaunchKernelGGL((fb_polyexp_m0<T>), grid, dim3(K1_THREADS), 0, ctx->stream, prev, next, g, pc, ws);
-    }
     const size_t lds_v = (size_t)(BV_NW * BV_R + 2 * m + 4) * 64 * sizeof(float);
     const int colsh = BH_NW * BH_R + 2 * m + 4;
     size_t lds_h = (size_t)64 * (colsh | 1) * sizeof(float);
     const size_t lds_t = (size_t)5 * 32 * (BH_NW * BH_R + 1) * sizeof(float);
     if (lds_t > lds_h) lds_h = lds_t;
     const bool fast = m >= 1 && lds_v <= LDS_MAX && lds_h <= LDS_MAX && colsh <= 320;  // 320 = 5 chunks (winsize <= 253)
+    // the LDS-staged kernels honour the active extent; the fallback kernels process whole windows
+#ifdef MA_NO_EXTENT
+    g.margin = 1 << 28;
+#else
+    g.margin = fast ? (iters - 1) * m + 3 : (1 << 28);
+#endif
+    {
+        MaProfScope ps(ctx, MA_K_POLYEXP_M0, px);
+        dim3 grid((Pw + K1_TX - 1) / K1_TX, (Ph + K1_TY - 1) / K1_TY, nwin);
+        hipLaunchKernelGGL((fb_polyexp_m0<T>), grid, dim3(K1_THREADS), 0, ctx->stream, prev, next, g, pc, ws);
+    }
     for (int it = 0; it < iters; it++) {
         const int last = it == iters - 1;
         if (fast) {
             {
                 MaProfScope ps(ctx, MA_K_BLUR_V, px);
-                const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * nwin * 5;
+                const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * ma_xcd_slots(nwin * 5);
                 hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_v,
                                    ctx->stream, g, m, taps, ws, nwin * 5);
             }
             {
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px);
-                const long long items = (long long)((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R)) * ((Ph + 63) / 64) * nwin;
+                const long long items = (long long)((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R)) * ((Ph + 63) / 64) * ma_xcd_slots(nwin);
                 if (colsh <= 192)
                     hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 3>), dim3(ma_xcd_grid(items)),
                                        dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin);
@@ -679,6 +724,7 @@ int farneback_impl(ma_ctx* ctx, const void* prev, const void* next, int dtype, i
     g.t = ma_make_tiling(H, W, tile, overlap);
     g.pitch = (int)ma_align_up((size_t)g.t.Pw, 64);
     g.plane = (size_t)g.t.Ph * g.pitch;
+    g.margin = 1 << 28;  // set per batch family in run_batch
     const int nwin_total = g.t.ntx * g.t.nty;
     const size_t per_win = g.plane * PL_COUNT * sizeof(float);
     MA_REQUIRE(per_win <= ctx->ws_limit, "one window does not fit the workspace limit");

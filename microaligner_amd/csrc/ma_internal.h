@@ -286,6 +286,16 @@ __device__ __forceinline__ int d_xcd_work_item(int b, int n_items)
 }
 static inline unsigned ma_xcd_grid(long long n_items) { return (unsigned)(((n_items + 7) / 8) * 8); }
 
+// Slot -> unit permutation for work lists whose units (windows, planes) have unequal cost (border windows are
+// mostly skipped, see window_extent): with units padded to a multiple of 8, XCD k's contiguous range of the list
+// holds the units k, k+8, k+16, ... so cheap and expensive units are spread evenly over the XCDs.
+__device__ __forceinline__ int d_xcd_unit(int slot, int n_units)
+{
+    const int per = (n_units + 7) >> 3;
+    return (slot % per) * 8 + slot / per;  // >= n_units for padding slots
+}
+static inline long long ma_xcd_slots(long long n_units) { return ((n_units + 7) / 8) * 8; }
+
 // Tile geometry shared by the tiled kernels (slicer.py / stitcher.py semantics).
 struct MaTiling {
     int H, W;      // image size
