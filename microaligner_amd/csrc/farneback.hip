@@ -15,6 +15,7 @@
 // -ffp-contract=off), so results are bit-identical to oracle/ma_oracle.c.
 #include "ma_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cfloat>
 
@@ -111,7 +112,7 @@ __device__ __forceinline__ void update_matrices_px(const float r0[5], float r2, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(K1_THREADS) void fb_polyexp_m0(const T* __restrict__ prev, const T* __restrict__ next,
+__global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restrict__ prev, const T* __restrict__ next,
                                                             FbGeom g, PolyConsts pc, float* __restrict__ ws)
 {
     constexpr int RW = K1_TX + 4, RH = K1_TY + 4;   // raw tile
@@ -130,48 +131,74 @@ __global__ __launch_bounds__(K1_THREADS) void fb_polyexp_m0(const T* __restrict_
     window_extent(g, oy, ox, ey, ex);
     if (x0 >= ex || y0 >= ey) return;  // nothing but exact zeros there
 
-    const int lx = tid & 63, lyg = tid >> 6;  // output mapping: column lx, rows lyg*4 .. lyg*4+3
-    float r0v[4][5];
+    const int lx = tid & 63;
+    const int lyg = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index; output mapping: column lx, rows lyg*4 .. +3
+    float r0v[4][5];  // R0 of this thread's four pixels, kept for the first UpdateMatrices in the second pass
+
+    // Staging index math is done once: each wave owns rows lyg, lyg+4, ... of every LDS tile (row math on the
+    // SALU) and a lane owns column lx; the 2-4 halo columns past 64 are handled by the first 4*rows (2*rows)
+    // threads of the block, one element each, so no wave issues a nearly empty instruction.
+    const int rtx0 = d_reflect101(x0 - 2 + lx, Pw);
+    const int tcx0 = d_clamp(d_clamp(x0 - 1 + lx, 0, Pw - 1) - (x0 - 2), 1, RW - 2);
+    // halo element of this thread: raw tile row tid/4, column 64 + tid%4; other tiles row tid/2, column 64 + tid%2
+    const int hr4 = tid >> 2, hc4 = 64 + (tid & 3), hr2 = tid >> 1, hc2 = 64 + (tid & 1);
+    const int rtxh = d_reflect101(x0 - 2 + hc4, Pw);
+    const int tcxh = d_clamp(d_clamp(x0 - 1 + hc2, 0, Pw - 1) - (x0 - 2), 1, RW - 2);
 
     for (int img = 0; img < 2; img++) {
         const T* src = img == 0 ? prev : next;
         // 1. raw tile at virtual coordinates (reflect-101 of the window), zero outside the image
-        for (int i = tid; i < RH * RW; i += K1_THREADS) {
-            int j = i / RW, c = i - j * RW;
-            int ty = d_reflect101(y0 - 2 + j, Ph), tx = d_reflect101(x0 - 2 + c, Pw);
-            raw[j][c] = fetch_window(src, g.t, oy, ox, ty, tx);
+        {
+            float v[RH / 4], vh = 0.f;
+#pragma unroll
+            for (int k = 0; k < RH / 4; k++)
+                v[k] = fetch_window(src, g.t, oy, ox, d_reflect101(y0 - 2 + lyg + 4 * k, Ph), rtx0);
+            if (hr4 < RH) vh = fetch_window(src, g.t, oy, ox, d_reflect101(y0 - 2 + hr4, Ph), rtxh);
+#pragma unroll
+            for (int k = 0; k < RH / 4; k++) raw[lyg + 4 * k][lx] = v[k];
+            if (hr4 < RH) raw[hr4][hc4] = vh;
         }
         __syncthreads();
         // 2. horizontal [1/4 1/2 1/4] at clamped columns
-        for (int i = tid; i < RH * TW; i += K1_THREADS) {
-            int j = i / TW, c = i - j * TW;
-            int cx = d_clamp(x0 - 1 + c, 0, Pw - 1) - (x0 - 2);
-            cx = d_clamp(cx, 1, RW - 2);  // only out-of-window rows of a partial block can hit this
-            tb[j][c] = raw[j][cx] * 0.5f + (raw[j][cx - 1] + raw[j][cx + 1]) * 0.25f;
+#pragma unroll
+        for (int k = 0; k < RH / 4; k++) {
+            const int j = lyg + 4 * k;
+            tb[j][lx] = raw[j][tcx0] * 0.5f + (raw[j][tcx0 - 1] + raw[j][tcx0 + 1]) * 0.25f;
         }
+        if (hr2 < RH) tb[hr2][hc2] = raw[hr2][tcxh] * 0.5f + (raw[hr2][tcxh - 1] + raw[hr2][tcxh + 1]) * 0.25f;
         __syncthreads();
         // 3. vertical [1/4 1/2 1/4] at clamped rows -> blurred image (replicate semantics for step 4/5)
-        for (int i = tid; i < (K1_TY + 2) * TW; i += K1_THREADS) {
-            int j = i / TW, c = i - j * TW;
-            int cy = d_clamp(y0 - 1 + j, 0, Ph - 1) - (y0 - 2);
-            cy = d_clamp(cy, 1, RH - 2);
-            bl[j][c] = tb[cy][c] * 0.5f + (tb[cy - 1][c] + tb[cy + 1][c]) * 0.25f;
+#pragma unroll
+        for (int k = 0; k < (K1_TY + 2 + 3) / 4; k++) {
+            const int j = lyg + 4 * k;
+            if (j < K1_TY + 2) {
+                const int cy = d_clamp(d_clamp(y0 - 1 + j, 0, Ph - 1) - (y0 - 2), 1, RH - 2);
+                bl[j][lx] = tb[cy][lx] * 0.5f + (tb[cy - 1][lx] + tb[cy + 1][lx]) * 0.25f;
+            }
+        }
+        if (hr2 < K1_TY + 2) {
+            const int cy = d_clamp(d_clamp(y0 - 1 + hr2, 0, Ph - 1) - (y0 - 2), 1, RH - 2);
+            bl[hr2][hc2] = tb[cy][hc2] * 0.5f + (tb[cy - 1][hc2] + tb[cy + 1][hc2]) * 0.25f;
         }
         __syncthreads();
         // 4. vertical part of the polynomial expansion (float)
-        for (int i = tid; i < K1_TY * TW; i += K1_THREADS) {
-            int j = i / TW, c = i - j * TW;
+        auto vpass = [&](int j, int c) {
             float up = bl[j][c], ce = bl[j + 1][c], dn = bl[j + 2][c];
             float p = up + dn;
             float row0 = ce * pc.g0;
             vt[0][j][c] = row0 + pc.g1 * p;
             vt[1][j][c] = 0.f + pc.xg1 * (dn - up);
             vt[2][j][c] = 0.f + pc.xxg1 * p;
-        }
+        };
+#pragma unroll
+        for (int k = 0; k < K1_TY / 4; k++) vpass(lyg + 4 * k, lx);
+        if (hr2 < K1_TY) vpass(hr2, hc2);
         __syncthreads();
         // 5. horizontal part (double accumulators where OpenCV has them) -> R
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
+            // one pixel at a time: without the fence the scheduler interleaves the four f64 sections (144 VGPRs)
+            __builtin_amdgcn_sched_barrier(0);
             const int j = lyg * 4 + rr;
             const int y = y0 + j, x = x0 + lx;
             const int c = lx + 1;
@@ -638,7 +665,6 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
 {
     float* ws = (float*)ctx->ws;
     const int Ph = g.t.Ph, Pw = g.t.Pw;
-    const double px = (double)nwin * Ph * Pw;
     const size_t lds_v = (size_t)(BV_NW * BV_R + 2 * m + 4) * 64 * sizeof(float);
     const int colsh = BH_NW * BH_R + 2 * m + 4;
     size_t lds_h = (size_t)64 * (colsh | 1) * sizeof(float);
@@ -651,6 +677,14 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
 #else
     g.margin = fast ? (iters - 1) * m + 3 : (1 << 28);
 #endif
+    // pixels actually processed (inside the active extents) -- the unit of the per-kernel accounting
+    double px = 0;
+    for (int wl = 0; wl < nwin; wl++) {
+        int oy = 0, ox = 0;
+        if (g.t.T > 0) { int ty = (g.tile0 + wl) / g.t.ntx, tx = (g.tile0 + wl) % g.t.ntx; oy = ty * g.t.T - g.t.ov; ox = tx * g.t.T - g.t.ov; }
+        const int vy = std::min(Ph, g.t.H - oy), vx = std::min(Pw, g.t.W - ox);
+        px += (double)std::min(Ph, vy + std::min(g.margin, Ph)) * std::min(Pw, vx + std::min(g.margin, Pw));
+    }
     {
         MaProfScope ps(ctx, MA_K_POLYEXP_M0, px);
         dim3 grid((Pw + K1_TX - 1) / K1_TX, (Ph + K1_TY - 1) / K1_TY, nwin);
