@@ -169,6 +169,13 @@ int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t 
 int ma_max_project(ma_ctx* ctx, const void* planes, int dtype, int nz, size_t n, void* dst);
 int ma_normalize_minmax_u8(ma_ctx* ctx, const void* src, int dtype, size_t n, uint8_t* dst);
 
+/* transform_img_with_tmat (utils.py:98-114) after padding: skimage.transform.warp(img,
+ * AffineTransform(inverse_3x3), output_shape=img.shape, preserve_range=True).astype(dtype) -- bilinear,
+ * constant border 0, clipped to the input range.  inverse_3x3_host: 9 doubles, row major, the matrix the
+ * reference obtains from np.linalg.pinv (output pixel -> input coordinate). */
+int ma_warp_affine(ma_ctx* ctx, const void* src, int dtype, int h, int w, const double* inverse_3x3_host,
+                   void* dst);
+
 #ifdef __cplusplus
 }
 #endif

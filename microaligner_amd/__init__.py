@@ -8,7 +8,8 @@ Compute runs in hand-written HIP kernels for gfx950 behind a C-ABI (include/micr
 there is no CPU fallback.
 """
 from .optflow_reg import OptFlowRegistrator, TileFlowCalc, Warper, farneback, merge_two_flows
-from .shared_modules.utils import pad_to_shape
+from .shared_modules.utils import pad_to_shape, transform_img_with_tmat
 
-__all__ = ["OptFlowRegistrator", "Warper", "TileFlowCalc", "farneback", "merge_two_flows", "pad_to_shape"]
+__all__ = ["OptFlowRegistrator", "Warper", "TileFlowCalc", "farneback", "merge_two_flows", "pad_to_shape",
+           "transform_img_with_tmat"]
 __version__ = "0.1.0"

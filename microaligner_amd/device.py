@@ -272,6 +272,14 @@ class Context:
         L.check(self.lib.ma_max_project(self.handle, stack.ptr, _dt(stack.dtype), nz, out.size, out.ptr))
         return out
 
+    def warp_affine(self, img, inverse_3x3):
+        """skimage.transform.warp(img, AffineTransform(inverse_3x3), preserve_range=True).astype(img.dtype)."""
+        h, w = img.shape
+        m = (C.c_double * 9)(*[float(v) for v in np.asarray(inverse_3x3, dtype=np.float64).ravel()])
+        out = self.empty((h, w), img.dtype)
+        L.check(self.lib.ma_warp_affine(self.handle, img.ptr, _dt(img.dtype), h, w, m, out.ptr))
+        return out
+
     def normalize_minmax_u8(self, arr):
         out = self.empty(arr.shape, np.uint8)
         L.check(self.lib.ma_normalize_minmax_u8(self.handle, arr.ptr, _dt(arr.dtype), arr.size, out.ptr))

@@ -119,6 +119,11 @@ class OptFlowRegistrator:
         mov_pyr, _ = self._generate_img_pyr(mov_full)
 
         n_lvl = len(factors)
+        if n_lvl == 0:
+            # the reference dies here with UnboundLocalError (m_flow is never assigned, optflow_registrator.py:173)
+            raise ValueError(
+                f"image of shape {tuple(ref_full.shape)} is too small for num_pyr_lvl={self.num_pyr_lvl} "
+                "(every pyramid level must keep >= 100 px per side) and use_full_res_img is False")
         m_flow: Optional[DeviceArray] = None
         for lvl, factor in enumerate(factors):  # smallest level first
             self._log("Pyramid factor", factor)

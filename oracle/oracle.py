@@ -98,8 +98,10 @@ def calc_optical_flow_farneback(prev, nxt, winsize, iterations, poly_n=1, poly_s
                                 dump=False):
     prev, dt = _img(prev)
     nxt, dt2 = _img(nxt)
-    if prev.shape != nxt.shape or dt != dt2 or prev.ndim != 2:
-        raise ValueError("prev/next must be 2-D, same shape and dtype")
+    if dt != dt2:  # OpenCV converts each image to float32 on its own (convertTo): mixed dtypes are legal
+        prev, nxt, dt = prev.astype(np.float32), nxt.astype(np.float32), F32
+    if prev.shape != nxt.shape or prev.ndim != 2:
+        raise ValueError("prev/next must be 2-D and of the same shape")
     h, w = prev.shape
     flow = np.empty((h, w, 2), np.float32)
     if dump:
@@ -118,7 +120,9 @@ def farneback_batch(prev_tiles, next_tiles, winsize, iterations, poly_n=1, poly_
                     nthreads=1):
     """prev_tiles/next_tiles: (n, h, w) arrays.  Returns (n, h, w, 2) float32."""
     prev_tiles, dt = _img(prev_tiles)
-    next_tiles, _ = _img(next_tiles)
+    next_tiles, dt2 = _img(next_tiles)
+    if dt != dt2:
+        prev_tiles, next_tiles, dt = prev_tiles.astype(np.float32), next_tiles.astype(np.float32), F32
     n, h, w = prev_tiles.shape
     flow = np.empty((n, h, w, 2), np.float32)
     _check(lib().orc_farneback_batch(_p(prev_tiles), _p(next_tiles), dt, n, h, w, winsize, iterations,

@@ -134,3 +134,28 @@ def test_full_size_properties_4096(ctx):
     d = ctx.dog_u8(dref)
     s = ctx.nmi_scores(d, d, 1000 * 1000)
     assert s.shape == (17,) and np.allclose(s, 1.0, atol=1e-12)
+
+
+def test_image_too_small_for_any_level_is_a_value_error():
+    ref, mov = synthetic.make_pair(150, 150, 1)
+    reg = make_reg(dict(num_pyr_lvl=3, use_full_res_img=False))
+    reg.ref_img, reg.mov_img = ref, mov
+    with pytest.raises(ValueError, match="too small"):
+        reg.register()
+
+
+def test_all_zero_moving_image_and_noncontiguous_inputs(ctx):
+    ref, _ = synthetic.make_pair(300, 280, 3)
+    zero = np.zeros_like(ref)
+    params = dict(num_pyr_lvl=1, use_full_res_img=True, use_dog=True, tile_size=100, overlap=14)
+    exp, reports = RO.register(ref, zero, **params)
+    reg = make_reg(params)
+    reg.ref_img, reg.mov_img = ref, zero
+    got = reg.register()
+    assert [r.accepted for r in reg.level_reports] == [r[3] for r in reports]
+    assert np.array_equal(got, exp)
+    # non-contiguous views are accepted like any ndarray
+    big_r, big_m = synthetic.make_pair(300, 560, 4)
+    reg.ref_img, reg.mov_img = big_r[:, ::2], big_m[:, ::2]
+    exp2, _ = RO.register(np.ascontiguousarray(big_r[:, ::2]), np.ascontiguousarray(big_m[:, ::2]), **params)
+    assert np.array_equal(reg.register(), exp2)
