@@ -129,6 +129,13 @@ int ma_remap_bilinear(ma_ctx* ctx, const void* src, int dtype, int cn, int sh, i
 int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow,
                   int tile, int overlap, void* out);
 
+/* Page-warp driver, warp_and_save_pages (__main__.py:288-302, 427-433): warps n_pages HOST images (the channel
+ * and z pages of one cycle) with ONE device-resident flow, writing into caller-provided HOST buffers (e.g. rows
+ * of the memmapped output TIFF).  H2D, kernel and D2H of consecutive pages overlap on internal streams.
+ * Synchronous: returns when every output page is complete. */
+int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* out_host, int n_pages, int dtype,
+                       int H, int W, const float* flow, int tile, int overlap);
+
 /* OptFlowRegistrator._merge_flow_in_tiles / merge_two_flows
  * (optflow_registrator.py:37-47,217-233): per window, out = flow2 if
  * flow1.max()==0, flow1 if flow2.max()==0, else flow1 + remap(flow2, -flow1). */

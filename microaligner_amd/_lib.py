@@ -46,6 +46,7 @@ SIGNATURES = {
     "ma_remap_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "ma_warp_tiled": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "ma_merge_flows_tiled": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ma_warp_pages_host": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _i, _i, _vp, _i, _i]),
     "ma_pyr_down": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "ma_pyr_up_flow": (_i, [_vp, _vp, _i, _i, _f, _vp, _i, _i]),
     "ma_minmax": (_i, [_vp, _vp, _i, _sz, C.POINTER(_d), C.POINTER(_d)]),

@@ -6,6 +6,8 @@
 // HBM-bound gathers: one destination pixel per thread, rows coalesced along x.
 #include "ma_internal.h"
 
+#include <cstring>
+
 namespace {
 
 struct Tap {
@@ -254,6 +256,64 @@ int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const f
     else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)img, g, f, (uint16_t*)out);
     else hipLaunchKernelGGL((warp_tiled_kernel<float>), grid, block, 0, ctx->stream, (const float*)img, g, f, (float*)out);
     MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+// ---- page-warp driver ---------------------------------------------------------------------
+// warp_and_save_pages (microaligner/__main__.py:288-302): every channel / z page of a cycle is warped with the
+// SAME flow.  The flow stays in HBM; pages stream through NS slots, each with its own HIP stream and device
+// buffer pair, so the H2D copy of page i+1, the kernel of page i and the D2H copy of page i-1 overlap.  Copies go
+// straight between the caller's buffers and HBM: on this platform resident pageable memory moves at the pinned
+// rate (56 GB/s, tools/ubench_pcie.hip), a pinned staging copy only adds a 28 GB/s memcpy and hipHostMalloc
+// costs 100 ms per 512 MiB.
+int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* out_host, int n_pages, int dtype,
+                       int H, int W, const float* flow, int tile, int overlap)
+{
+    MA_REQUIRE(ctx && pages_host && out_host && flow, "NULL argument");
+    MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
+    MA_REQUIRE(H > 0 && W > 0 && H <= 65535 && n_pages >= 0, "bad size");
+    MA_REQUIRE(tile >= 0 && overlap >= 0, "tile/overlap must be >= 0");
+    MaTiling g = ma_make_tiling(H, W, tile, overlap);
+    MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
+    for (int i = 0; i < n_pages; i++) MA_REQUIRE(pages_host[i] && out_host[i], "NULL page pointer");
+    if (n_pages == 0) return MA_OK;
+    MA_HIP(hipSetDevice(ctx->device));
+    constexpr int NS = 3;
+    const int ns = n_pages < NS ? n_pages : NS;
+    const size_t bytes = ma_align_up((size_t)H * W * ma_esize(dtype), 256);
+    MA_TRY(ma_ws_reserve(ctx, bytes * 2 * ns));  // device buffers come from the context workspace
+    struct Slot { hipStream_t st = nullptr; void *din = nullptr, *dout = nullptr; };
+    Slot slots[NS];
+    hipEvent_t flow_ready = nullptr;
+    auto cleanup = [&]() {
+        for (auto& s : slots)
+            if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
+        if (flow_ready) (void)hipEventDestroy(flow_ready);
+    };
+#define PG_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ma_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return MA_EHIP; } } while (0)
+    PG_HIP(hipEventCreateWithFlags(&flow_ready, hipEventDisableTiming));
+    PG_HIP(hipEventRecord(flow_ready, ctx->stream));  // the flow may still be in flight on the ctx stream
+    for (int k = 0; k < ns; k++) {
+        PG_HIP(hipStreamCreateWithFlags(&slots[k].st, hipStreamNonBlocking));
+        slots[k].din = (char*)ctx->ws + bytes * (2 * k);
+        slots[k].dout = (char*)ctx->ws + bytes * (2 * k + 1);
+        PG_HIP(hipStreamWaitEvent(slots[k].st, flow_ready, 0));
+    }
+    const float2* f = (const float2*)flow;
+    const size_t nb = (size_t)H * W * ma_esize(dtype);
+    dim3 grid((W + 255) / 256, H), block(256);
+    for (int i = 0; i < n_pages; i++) {
+        Slot& s = slots[i % ns];  // stream order keeps the slot's buffers safe: copy-in waits for the previous copy-out
+        PG_HIP(hipMemcpyAsync(s.din, pages_host[i], nb, hipMemcpyHostToDevice, s.st));
+        if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t>), grid, block, 0, s.st, (const uint8_t*)s.din, g, f, (uint8_t*)s.dout);
+        else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t>), grid, block, 0, s.st, (const uint16_t*)s.din, g, f, (uint16_t*)s.dout);
+        else hipLaunchKernelGGL((warp_tiled_kernel<float>), grid, block, 0, s.st, (const float*)s.din, g, f, (float*)s.dout);
+        PG_HIP(hipGetLastError());
+        PG_HIP(hipMemcpyAsync(out_host[i], s.dout, nb, hipMemcpyDeviceToHost, s.st));
+    }
+    for (int k = 0; k < ns; k++) PG_HIP(hipStreamSynchronize(slots[k].st));
+#undef PG_HIP
+    cleanup();
     return MA_OK;
 }
 

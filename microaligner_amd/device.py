@@ -217,6 +217,30 @@ class Context:
                                        int(overlap), out.ptr))
         return out
 
+    def warp_pages(self, pages, flow, tile, overlap, out=None):
+        """warp_and_save_pages (__main__.py:288-302): warp every HOST page with one device-resident flow.
+        pages: sequence of equal-shape C-contiguous numpy arrays; out: optional sequence of writable arrays of the
+        same shape/dtype (e.g. memmap rows), allocated if None.  Returns `out`."""
+        pages = [np.ascontiguousarray(p) for p in pages]
+        if not pages:
+            return []
+        H, W = pages[0].shape
+        dt = _dt(pages[0].dtype)
+        if any(p.shape != (H, W) or p.dtype != pages[0].dtype for p in pages):
+            raise ValueError("all pages must have the same shape and dtype")
+        if flow.shape != (H, W, 2):
+            raise ValueError(f"flow must have shape {(H, W, 2)}")
+        if out is None:
+            out = [np.empty((H, W), pages[0].dtype) for _ in pages]
+        if len(out) != len(pages) or any(o.shape != (H, W) or o.dtype != pages[0].dtype or not o.flags.c_contiguous
+                                         or not o.flags.writeable for o in out):
+            raise ValueError("out must hold one writable C-contiguous array of the page shape/dtype per page")
+        n = len(pages)
+        src = (C.c_void_p * n)(*[p.ctypes.data for p in pages])
+        dst = (C.c_void_p * n)(*[o.ctypes.data for o in out])
+        L.check(self.lib.ma_warp_pages_host(self.handle, src, dst, n, dt, H, W, flow.ptr, int(tile), int(overlap)))
+        return out
+
     def merge_flows(self, flow1, flow2, tile, overlap):
         """_merge_flow_in_tiles (optflow_registrator.py:217-233)."""
         if flow1.shape != flow2.shape:

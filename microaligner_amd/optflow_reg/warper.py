@@ -31,3 +31,13 @@ class Warper:
         self.image = np.array([])
         self.flow = np.array([])
         return out if isinstance(like, DeviceArray) else out.numpy()
+
+    def warp_pages(self, pages, out=None):
+        """Apply `self.flow` to many pages (the channel x z pages of a cycle, __main__.py:288-302,427-433) with the
+        flow uploaded once and the page transfers overlapped.  Unlike warp() this keeps `self.flow`."""
+        if len(self.flow) == 0:
+            raise ValueError("No flow provided")
+        ctx = get_context()
+        flow = ctx.asdevice(self.flow)
+        self.flow = flow  # stays resident for further calls
+        return ctx.warp_pages(pages, flow, self.tile_size, self.overlap, out)

@@ -84,18 +84,26 @@ def register_pairs(pairs: Sequence, params: Optional[dict] = None, warp: bool = 
 
 
 def warp_pages(pages: Sequence, flow, tile_size: int = 1000, overlap: int = 100, gather: bool = True):
-    """Apply ONE flow to many pages (channels x z-planes of a cycle, __main__.py:288-302,427-433), pages dealt
-    round-robin to the ranks; each rank uploads the flow once and keeps it in HBM for all of its pages."""
-    from . import Warper
+    """Apply ONE flow to many pages (channels x z-planes of a cycle, __main__.py:288-302,427-433).  Pages are dealt
+    round-robin to the ranks; each rank uploads the flow once and streams its share through the overlapped
+    page-warp driver (ma_warp_pages_host).  Returns the warped pages in page order on rank 0 (gather=True) or
+    {page_index: array} for the local share."""
     from .device import get_context
-    state = {}
-
-    def one(page):
-        if "flow" not in state:
-            state["flow"] = get_context().asdevice(flow)
-        w = Warper()
-        w.tile_size, w.overlap = tile_size, overlap
-        w.image, w.flow = get_context().asdevice(page), state["flow"]
-        return w.warp().numpy()
-
-    return run_sharded(pages, one, gather=gather)
+    rank, ws = world()
+    mine = shard(len(pages), rank, ws)
+    ctx = get_context()
+    outs = ctx.warp_pages([pages[i] for i in mine], ctx.asdevice(flow), tile_size, overlap) if mine else []
+    local = dict(zip(mine, outs))
+    if not gather:
+        return local
+    if ws == 1:
+        return [local[i] for i in range(len(pages))]
+    import torch.distributed as dist
+    bucket = [None] * ws if rank == 0 else None
+    dist.gather_object(local, bucket, dst=0)
+    if rank != 0:
+        return None
+    merged = {}
+    for part in bucket:
+        merged.update(part)
+    return [merged[i] for i in range(len(pages))]

@@ -159,3 +159,27 @@ def test_all_zero_moving_image_and_noncontiguous_inputs(ctx):
     reg.ref_img, reg.mov_img = big_r[:, ::2], big_m[:, ::2]
     exp2, _ = RO.register(np.ascontiguousarray(big_r[:, ::2]), np.ascontiguousarray(big_m[:, ::2]), **params)
     assert np.array_equal(reg.register(), exp2)
+
+
+def test_page_warp_driver_matches_single_page_warps(ctx):
+    """one device-resident flow applied to many host pages (u16, the pipeline's page dtype)."""
+    H, W = 333, 290
+    rng = np.random.default_rng(5)
+    pages = [rng.integers(0, 65535, (H, W)).astype(np.uint16) for _ in range(7)]
+    from scipy.ndimage import gaussian_filter
+    flow = np.stack([gaussian_filter(rng.standard_normal((H, W)), 6) * 40, gaussian_filter(rng.standard_normal((H, W)), 6) * 40],
+                    -1).astype(np.float32)
+    w = Warper()
+    w.tile_size, w.overlap = 100, 12
+    w.flow = flow
+    out = w.warp_pages(pages)
+    assert len(out) == 7
+    for p, o in zip(pages, out):
+        assert o.dtype == np.uint16 and np.array_equal(o, RO.warp(p, flow, 100, 12))
+    # caller-provided output rows (the memmapped TIFF in the pipeline), second call reuses the resident flow
+    dst = np.zeros((7, H, W), np.uint16)
+    w.warp_pages(pages, out=[dst[i] for i in range(7)])
+    assert np.array_equal(dst, np.stack(out))
+    assert w.warp_pages([]) == []
+    with pytest.raises(ValueError):
+        w.warp_pages([pages[0][:10]])
