@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override H=W of the workload")
     ap.add_argument("--fused", action="store_true", help="window blur with FMA (MA_FB_MULADD_FUSED)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dog", action="store_true", help="experiment: run the workload with use_dog=False")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     args = ap.parse_args()
 
@@ -127,6 +128,8 @@ def main():
     wl = WORKLOADS[args.workload]
     H, W = (args.size, args.size) if args.size else wl["shape"]
     params = dict(wl["params"])
+    if args.no_dog:
+        params["use_dog"] = False
     ctx = get_context(local_rank)
 
     ref, mov = synthetic.make_pair(H, W, seed=1 + rank)
@@ -177,7 +180,7 @@ def main():
         iters, esz = reg.num_iterations, 4
         # with use_dog the Farneback inputs are the uint8 DOG images (1 B/px), not the f32 level images
         fb_esz = 1 if reg.use_dog else esz
-        tps = pmc_traffic(args.workload) if not args.size and not args.fused else {}
+        tps = pmc_traffic(args.workload) if not args.size and not args.fused and not args.no_dog else {}
         kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz, args.steps, tps)
                    for k, v in prof.items()}
         kernels = {k: v for k, v in kernels.items() if v}

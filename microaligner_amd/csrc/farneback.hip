@@ -145,10 +145,28 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
     const int rtxh = d_reflect101(x0 - 2 + hc4, Pw);
     const int tcxh = d_clamp(d_clamp(x0 - 1 + hc2, 0, Pw - 1) - (x0 - 2), 1, RW - 2);
 
+    // block whose 20 x 68 raw tile needs neither reflection nor zero padding
+    const bool interior = x0 >= 2 && x0 + K1_TX + 2 <= Pw && y0 >= 2 && y0 + K1_TY + 2 <= Ph && ox + x0 - 2 >= 0 &&
+                          ox + x0 + K1_TX + 2 <= g.t.W && oy + y0 - 2 >= 0 && oy + y0 + K1_TY + 2 <= g.t.H;
+
     for (int img = 0; img < 2; img++) {
         const T* src = img == 0 ? prev : next;
         // 1. raw tile at virtual coordinates (reflect-101 of the window), zero outside the image
-        {
+        if (sizeof(T) == 1 && interior) {
+            // uint8 images (the DOG inputs), block fully inside window and image: the 20 x 68 bytes are fetched as
+            // 20 x 17 (unaligned) dwords -- byte-per-lane loads cost this kernel ~35 % (profiles/r01_notes.md)
+            constexpr int DW = RW / 4;
+            const uint8_t* base = reinterpret_cast<const uint8_t*>(src) + (size_t)(oy + y0 - 2) * g.t.W + (ox + x0 - 2);
+            for (int e = tid; e < RH * DW; e += K1_THREADS) {
+                const int j = e / DW, dw = e - j * DW;
+                uint32_t word;
+                __builtin_memcpy(&word, base + (size_t)j * g.t.W + 4 * dw, 4);
+                raw[j][4 * dw + 0] = (float)(word & 255u);
+                raw[j][4 * dw + 1] = (float)((word >> 8) & 255u);
+                raw[j][4 * dw + 2] = (float)((word >> 16) & 255u);
+                raw[j][4 * dw + 3] = (float)(word >> 24);
+            }
+        } else {
             float v[RH / 4], vh = 0.f;
 #pragma unroll
             for (int k = 0; k < RH / 4; k++)
