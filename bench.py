@@ -203,6 +203,20 @@ def main():
             "kernels": kernels,
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 3),
         }
+        if world == 1 and not args.fused:
+            # informational: the same workload with the window blur in the FMA rounding model
+            # (MA_FB_MULADD_FUSED: OpenCV builds whose v_muladd is a fused multiply-add); not the headline value
+            reg.muladd_fused = True
+            step()
+            ctx.sync()
+            tf0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            ctx.sync()
+            tf = (time.perf_counter() - tf0) / args.steps
+            reg.muladd_fused = False
+            res["variants"] = {"muladd_fma": {"value": round(H * W / tf / 1e6, 2), "unit": "Mpix/s",
+                                              "ms_per_step": round(tf * 1e3, 3)}}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample, params)
         print(json.dumps(res))

@@ -265,11 +265,10 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
 // Lanes run along x; each thread owns one column and R consecutive output rows, sliding a register
 // window over an LDS-staged column strip:  s = c*k0;  s = (dn_i + up_i)*k_i + s  for i = 1..m.
 // ---------------------------------------------------------------------------------------------
-#ifndef MA_BV_WAVES
-#define MA_BV_WAVES 6
-#endif
+// occupancy targets (waves per SIMD) passed to __launch_bounds__; tuned on MI355X (profiles/r01_notes.md)
+constexpr int BV_WAVES = 6, BH_WAVES = 6;
 template <int R, int NW, bool FUSED>
-__global__ __launch_bounds__(64 * NW, MA_BV_WAVES) void fb_blur_v(FbGeom g, int m, const float* __restrict__ taps,
+__global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v(FbGeom g, int m, const float* __restrict__ taps,
                                                      float* __restrict__ ws, int nplanes)
 {
     extern __shared__ float lds[];  // [(NW*R + 2m)][64]
@@ -300,13 +299,9 @@ __global__ __launch_bounds__(64 * NW, MA_BV_WAVES) void fb_blur_v(FbGeom g, int 
     const int rows = NW * R + 2 * m + 2 * G;
     const int xc = min(x0 + lane, Pw - 1);
     const bool xin = xc < ex;
-#ifndef MA_ABL_NOSTAGE
     {
         // rows in batches of SB per wave: all SB global loads are issued before the first LDS store
-#ifndef MA_BV_SB
-#define MA_BV_SB 42
-#endif
-        constexpr int SB = MA_BV_SB;
+        constexpr int SB = 42;
         const unsigned xo = (unsigned)xc * 4u;  // row base is wave-uniform (SGPR), the lane byte offset is 32 bit
         for (int j0 = w; j0 < rows; j0 += NW * SB) {
             float v[SB];
@@ -321,15 +316,10 @@ __global__ __launch_bounds__(64 * NW, MA_BV_WAVES) void fb_blur_v(FbGeom g, int 
                 if (j0 + NW * k < rows) lds[(j0 + NW * k) * 64 + lane] = v[k];
         }
     }
-#endif
     __syncthreads();
 
     float acc[R];
-#ifndef MA_ABL_NOFIR
     d_sym_fir_slide_pk<R, FUSED, true>(lds + lane, G + m + w * R, m, taps, acc);
-#else
-    for (int r = 0; r < R; r++) acc[r] = lds[(G + m + w * R + r) * 64 + lane];
-#endif
     const int x = x0 + lane;
     if (x < Pw) {
 #pragma unroll
@@ -346,15 +336,9 @@ __global__ __launch_bounds__(64 * NW, MA_BV_WAVES) void fb_blur_v(FbGeom g, int 
 // through LDS so that all global traffic (R0, R1 gather, M / flow stores) is coalesced along x.
 // Block: 64 rows x (NW*R) columns.
 // ---------------------------------------------------------------------------------------------
-#ifndef MA_BH_WAVES
-#define MA_BH_WAVES 6
-#endif
-#ifndef MA_BH_PREFETCH
-#define MA_BH_PREFETCH 0
-#endif
 // Q = ceil((NW*R + 2m + 4) / 64): column chunks of the staged row tile
 template <int R, int NW, bool FUSED, int Q>
-__global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g, int m, const float* __restrict__ taps,
+__global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, int m, const float* __restrict__ taps,
                                                            float* __restrict__ ws, int last,
                                                            float* __restrict__ flow_out, int nwin)
 {
@@ -382,8 +366,8 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
     const int lp = cols | 1;              // odd LDS pitch: lanes (rows) hit distinct banks
 
     // Staging of one plane: 64/NW rows x Q column chunks per wave; every global load is issued before the first
-    // LDS store, and the loads of plane ch+1 are issued before plane ch is filtered (register prefetch), so their
-    // latency hides behind the FIR.
+    // LDS store.  (Issuing plane ch+1's loads before plane ch is filtered -- register prefetch -- was measured: no gain
+    // at 4 waves/SIMD, spills at 6.)
     constexpr int RW = 64 / NW;
     float v[RW][Q];
     int xi[Q];
@@ -415,17 +399,12 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
     for (int ch = 0; ch < 5; ch++) {
         commit();
         __syncthreads();
-#if MA_BH_PREFETCH
-        if (ch < 4) issue(ch + 1);
-#endif
         float acc[R];
         d_sym_fir_slide_pk<R, FUSED, false>(lds + lane * lp, G + m + w * R, m, taps, acc);
 #pragma unroll
         for (int r = 0; r < R; r++) hs[ch][r] = acc[r];
         __syncthreads();
-#if !MA_BH_PREFETCH
         if (ch < 4) issue(ch + 1);
-#endif
     }
 
     // transpose through LDS in two halves of 32 rows: tb[ch][32][TXW+1]
@@ -433,14 +412,6 @@ __global__ __launch_bounds__(64 * NW, MA_BH_WAVES) void fb_blur_h_solve(FbGeom g
     const float* R0p = plane_ptr(ws, g, wl, PL_R0);
     const float* R1p = plane_ptr(ws, g, wl, PL_R1);
     float* Mp = plane_ptr(ws, g, wl, PL_M);
-#ifdef MA_ABL_NOFINAL
-    {
-        float s = 0;
-        for (int ch = 0; ch < 5; ch++) for (int r = 0; r < R; r++) s += hs[ch][r];
-        if (s == 123.456f) Mp[tid] = s;
-        return;
-    }
-#endif
     for (int half = 0; half < 2; half++) {
         if ((lane >> 5) == half) {
 #pragma unroll
@@ -667,13 +638,7 @@ void make_window_taps(int winsize, std::vector<float>& k)
     for (int i = 0; i <= m; i++) k[i] = (float)(k[i] * s);
 }
 
-#ifndef MA_BV_NW
-#define MA_BV_NW 4
-#endif
-#ifndef MA_BV_R
-#define MA_BV_R 16
-#endif
-constexpr int BV_R = MA_BV_R, BV_NW = MA_BV_NW;   // fb_blur_v: 64 columns x (NW*R) rows per block
+constexpr int BV_R = 16, BV_NW = 4;   // fb_blur_v: 64 columns x (NW*R) = 64 rows per block
 constexpr int BH_R = 8, BH_NW = 8;    // fb_blur_h_solve: 64 rows x 64 columns per block
 constexpr size_t LDS_MAX = 160 * 1024;
 
@@ -690,11 +655,7 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
     if (lds_t > lds_h) lds_h = lds_t;
     const bool fast = m >= 1 && lds_v <= LDS_MAX && lds_h <= LDS_MAX && colsh <= 320;  // 320 = 5 chunks (winsize <= 253)
     // the LDS-staged kernels honour the active extent; the fallback kernels process whole windows
-#ifdef MA_NO_EXTENT
-    g.margin = 1 << 28;
-#else
     g.margin = fast ? (iters - 1) * m + 3 : (1 << 28);
-#endif
     // pixels actually processed (inside the active extents) -- the unit of the per-kernel accounting
     double px = 0;
     for (int wl = 0; wl < nwin; wl++) {
