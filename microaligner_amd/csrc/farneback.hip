@@ -302,13 +302,16 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v(FbGeom g, int m, 
     {
         // rows in batches of SB per wave: all SB global loads are issued before the first LDS store
         constexpr int SB = 42;
-        const unsigned xo = (unsigned)xc * 4u;  // row base is wave-uniform (SGPR), the lane byte offset is 32 bit
+        const unsigned xo = (unsigned)xc * 4u;  // lane byte offset inside a row
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0,
+                                                                               (int)(g.plane * sizeof(float)), 0x00020000);
         for (int j0 = w; j0 < rows; j0 += NW * SB) {
             float v[SB];
 #pragma unroll
             for (int k = 0; k < SB; k++) {
                 const int y = d_clamp(y0 - m - G + j0 + NW * k, 0, Ph - 1);
-                v[k] = d_ldg(src + (size_t)min(y, ey - 1) * g.pitch, xo);
+                // buffer load: the row offset rides in an SGPR, the lane offset is one VGPR for all rows
+                v[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xo, min(y, ey - 1) * g.pitch * 4, 0));
                 if (y >= ey || !xin) v[k] = 0.f;  // beyond the active extent M is exactly zero (and was not written)
             }
 #pragma unroll
@@ -321,11 +324,12 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v(FbGeom g, int m, 
     float acc[R];
     d_sym_fir_slide_pk<R, FUSED, true>(lds + lane, G + m + w * R, m, taps, acc);
     const int x = x0 + lane;
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(g.plane * sizeof(float)), 0x00020000);
     if (x < Pw) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int y = y0 + w * R + r;
-            if (y < Ph) d_stg(dst + (size_t)y * g.pitch, (unsigned)x * 4u, acc[r]);
+            if (y < Ph) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), drsrc, x * 4, y * g.pitch * 4, 0);
         }
     }
 }
@@ -370,18 +374,26 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
     // at 4 waves/SIMD, spills at 6.)
     constexpr int RW = 64 / NW;
     float v[RW][Q];
-    int xi[Q];
+    // one buffer resource spans the window's 20 planes: plane and row offsets ride in SGPRs, each access needs
+    // only a 32-bit lane offset (no 64-bit VALU address arithmetic)
+    const int plane4 = (int)(g.plane * sizeof(float));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr(ws, g, wl, 0), 0, PL_COUNT * plane4, 0x00020000);
+    int xo[Q];       // lane byte offset of column chunk q (clamped into the active extent)
+    bool xz[Q];      // chunk column lies right of the active extent: V is exactly zero there
 #pragma unroll
-    for (int q = 0; q < Q; q++) xi[q] = d_clamp(x0 - m - G + lane + 64 * q, 0, Pw - 1);
+    for (int q = 0; q < Q; q++) {
+        const int xi = d_clamp(x0 - m - G + lane + 64 * q, 0, Pw - 1);
+        xz[q] = xi >= ex;
+        xo[q] = min(xi, ex - 1) * 4;
+    }
     auto issue = [&](int ch) {
-        const float* src = plane_ptr(ws, g, wl, PL_V + ch);
 #pragma unroll
         for (int k = 0; k < RW; k++) {
-            const float* srow = src + (size_t)min(y0 + w + NW * k, Ph - 1) * g.pitch;
+            const int soff = (PL_V + ch) * plane4 + min(y0 + w + NW * k, Ph - 1) * g.pitch * 4;
 #pragma unroll
             for (int q = 0; q < Q; q++) {
-                v[k][q] = srow[min(xi[q], ex - 1)];
-                if (xi[q] >= ex) v[k][q] = 0.f;  // V is exactly zero right of the active extent
+                v[k][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, xo[q], soff, 0));
+                if (xz[q]) v[k][q] = 0.f;
             }
         }
     };
@@ -409,9 +421,6 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
 
     // transpose through LDS in two halves of 32 rows: tb[ch][32][TXW+1]
     constexpr int TP = TXW + 1;
-    const float* R0p = plane_ptr(ws, g, wl, PL_R0);
-    const float* R1p = plane_ptr(ws, g, wl, PL_R1);
-    float* Mp = plane_ptr(ws, g, wl, PL_M);
     for (int half = 0; half < 2; half++) {
         if ((lane >> 5) == half) {
 #pragma unroll
@@ -442,11 +451,11 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
                     }
                 } else {
                     // UpdateMatrices (A.1 step 3) at this pixel
-                    const unsigned plane = (unsigned)g.plane;
-                    const unsigned pix = (unsigned)y * (unsigned)g.pitch + (unsigned)x;
+                    const int pix4 = (y * g.pitch + x) * 4;
                     float r0[5];
 #pragma unroll
-                    for (int k = 0; k < 5; k++) r0[k] = R0p[k * plane + pix];
+                    for (int k = 0; k < 5; k++)
+                        r0[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, pix4, (PL_R0 + k) * plane4, 0));
                     float fx = (float)x + dx, fy = (float)y + dy;
                     int x1 = d_cvfloor(fx), y1 = d_cvfloor(fy);
                     fx -= (float)x1; fy -= (float)y1;
@@ -457,17 +466,22 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
                     if (inside && !r1zero) {
                         float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy,
                               a11 = fx * fy;
-                        const unsigned q0 = (unsigned)y1 * (unsigned)g.pitch + (unsigned)x1, q1 = q0 + (unsigned)g.pitch;
+                        const int q0 = (y1 * g.pitch + x1) * 4, q1 = q0 + g.pitch * 4;
 #pragma unroll
                         for (int k = 0; k < 5; k++) {
-                            const float* qk = R1p + k * plane;
-                            r[k] = a00 * qk[q0] + a01 * qk[q0 + 1] + a10 * qk[q1] + a11 * qk[q1 + 1];
+                            const int so = (PL_R1 + k) * plane4;
+                            const float s00 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, q0, so, 0));
+                            const float s01 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, q0 + 4, so, 0));
+                            const float s10 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, q1, so, 0));
+                            const float s11 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, q1 + 4, so, 0));
+                            r[k] = a00 * s00 + a01 * s01 + a10 * s10 + a11 * s11;
                         }
                     }
                     float Mv[5];
                     update_matrices_px(r0, r[0], r[1], r[2], r[3], r[4], inside, dx, dy, x, y, Pw, Ph, Mv);
 #pragma unroll
-                    for (int k = 0; k < 5; k++) Mp[k * plane + pix] = Mv[k];
+                    for (int k = 0; k < 5; k++)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Mv[k]), wrsrc, pix4, (PL_M + k) * plane4, 0);
                 }
             }
         }
