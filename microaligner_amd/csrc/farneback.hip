@@ -145,6 +145,9 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
     const int rtxh = d_reflect101(x0 - 2 + hc4, Pw);
     const int tcxh = d_clamp(d_clamp(x0 - 1 + hc2, 0, Pw - 1) - (x0 - 2), 1, RW - 2);
 
+    // stores go through one buffer resource spanning the window's planes (plane offsets in SGPRs)
+    const int plane4 = (int)(g.plane * sizeof(float));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr(ws, g, wl, 0), 0, PL_COUNT * plane4, 0x00020000);
     // block whose 20 x 68 raw tile needs neither reflection nor zero padding
     const bool interior = x0 >= 2 && x0 + K1_TX + 2 <= Pw && y0 >= 2 && y0 + K1_TY + 2 <= Ph && ox + x0 - 2 >= 0 &&
                           ox + x0 + K1_TX + 2 <= g.t.W && oy + y0 - 2 >= 0 && oy + y0 + K1_TY + 2 <= g.t.H;
@@ -238,10 +241,12 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
             R[2] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
             R[4] = (float)(b6 * pc.ig55);
             const bool ok = y < Ph && x < Pw;
+            const int pix4 = (y * g.pitch + x) * 4;
             if (ok) {
-                float* dst = plane_ptr(ws, g, wl, img == 0 ? PL_R0 : PL_R1) + (size_t)y * g.pitch + x;
 #pragma unroll
-                for (int k = 0; k < 5; k++) dst[k * g.plane] = R[k];
+                for (int k = 0; k < 5; k++)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(R[k]), wrsrc, pix4,
+                                                          ((img == 0 ? PL_R0 : PL_R1) + k) * plane4, 0);
             }
             if (img == 0) {
 #pragma unroll
@@ -251,9 +256,9 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
                 const bool inside = x < Pw - 1 && y < Ph - 1;
                 float Mv[5];
                 update_matrices_px(r0v[rr], R[0], R[1], R[2], R[3], R[4], inside, 0.f, 0.f, x, y, Pw, Ph, Mv);
-                float* dst = plane_ptr(ws, g, wl, PL_M) + (size_t)y * g.pitch + x;
 #pragma unroll
-                for (int k = 0; k < 5; k++) dst[k * g.plane] = Mv[k];
+                for (int k = 0; k < 5; k++)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Mv[k]), wrsrc, pix4, (PL_M + k) * plane4, 0);
             }
         }
         __syncthreads();
