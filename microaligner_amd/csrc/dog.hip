@@ -119,12 +119,22 @@ __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h
     const int r = ksize / 2, span = 256 + 2 * r;
     const int x0 = blockIdx.x * 256, y0 = blockIdx.y * DR;
     const float a = sc->a, b = sc->b;
-    for (int row = 0; row < DR; row++) {
-        const int y = min(y0 + row, h - 1);
-        const T* s = src + (size_t)y * w;
-        for (int c = threadIdx.x; c < span; c += 256) {
-            int x = d_reflect101(x0 - r + c, w);
-            lds[row * span + c] = __fadd_rn(__fmul_rn((float)s[x], a), b);
+    // column indices once per thread (a thread stages columns tid and tid + 256 of every row); all loads of the
+    // block are issued before the first LDS store
+    const int c1 = threadIdx.x + 256;
+    const int xa = d_reflect101(x0 - r + (int)threadIdx.x, w), xb = d_reflect101(x0 - r + min(c1, span - 1), w);
+    {
+        float va[DR], vb[DR];
+#pragma unroll
+        for (int row = 0; row < DR; row++) {
+            const T* s = src + (size_t)min(y0 + row, h - 1) * w;
+            va[row] = (float)s[xa];
+            vb[row] = (float)s[xb];
+        }
+#pragma unroll
+        for (int row = 0; row < DR; row++) {
+            lds[row * span + threadIdx.x] = __fadd_rn(__fmul_rn(va[row], a), b);
+            if (c1 < span) lds[row * span + c1] = __fadd_rn(__fmul_rn(vb[row], a), b);
         }
     }
     __syncthreads();
