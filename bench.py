@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--fused", action="store_true", help="window blur with FMA (MA_FB_MULADD_FUSED)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dog", action="store_true", help="experiment: run the workload with use_dog=False")
+    ap.add_argument("--no-variants", action="store_true", help="skip the informational FMA-mode leg (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     args = ap.parse_args()
 
@@ -203,7 +204,7 @@ def main():
             "kernels": kernels,
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 3),
         }
-        if world == 1 and not args.fused:
+        if world == 1 and not args.fused and not args.no_variants:
             # informational: the same workload with the window blur in the FMA rounding model
             # (MA_FB_MULADD_FUSED: OpenCV builds whose v_muladd is a fused multiply-add); not the headline value
             reg.muladd_fused = True

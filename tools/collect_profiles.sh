@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+CMD="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants"
 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- $CMD > $OUT/bench_under_kernel_trace.json 2> $OUT/kt.err
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- $CMD > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write --output-format csv -- $CMD > /dev/null 2> $OUT/write.err
