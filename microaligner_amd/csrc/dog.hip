@@ -29,14 +29,40 @@ __device__ __forceinline__ void block_minmax_256(float lo, float hi, float* out2
     }
 }
 
+// 16 bytes per lane and load; head/tail elements that do not fill an aligned 16-byte group go one by one
 template <typename T>
 __global__ __launch_bounds__(256) void minmax_partial(const T* __restrict__ src, size_t n, float* __restrict__ part)
 {
+    constexpr int E = 16 / sizeof(T);
     float lo = INFINITY, hi = -INFINITY;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v = (float)src[i];
-        lo = fminf(lo, v); hi = fmaxf(hi, v);
+    const size_t mis = ((size_t)src & 15) / sizeof(T);
+    size_t head = mis ? E - mis : 0;
+    if (head > n) head = n;
+    const size_t nvec = (n - head) / E;
+    const uint4* v = reinterpret_cast<const uint4*>(src + head);
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    for (size_t i = tid; i < nvec; i += stride) {
+        const uint4 q = v[i];
+        const unsigned wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if constexpr (sizeof(T) == 4) {
+                float f = __uint_as_float(wd[k]);
+                lo = fminf(lo, f); hi = fmaxf(hi, f);
+            } else if constexpr (sizeof(T) == 2) {
+                float f0 = (float)(wd[k] & 0xffffu), f1 = (float)(wd[k] >> 16);
+                lo = fminf(lo, fminf(f0, f1)); hi = fmaxf(hi, fmaxf(f0, f1));
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    float f = (float)((wd[k] >> (8 * b)) & 0xffu);
+                    lo = fminf(lo, f); hi = fmaxf(hi, f);
+                }
+            }
+        }
     }
+    for (size_t i = tid; i < head; i += stride) { float f = (float)src[i]; lo = fminf(lo, f); hi = fmaxf(hi, f); }
+    for (size_t i = head + nvec * E + tid; i < n; i += stride) { float f = (float)src[i]; lo = fminf(lo, f); hi = fmaxf(hi, f); }
     block_minmax_256(lo, hi, part + blockIdx.x * 2);
 }
 
@@ -226,17 +252,34 @@ __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict
     }
 }
 
-// dst = saturate_u8(round_half_even(src*a + b)); a/b either immediate or from the DOG scalars
+// dst = saturate_u8(round_half_even(src*a + b)); a/b either immediate or from the DOG scalars.
+// Groups of four pixels: 16-byte loads for float sources, one packed 4-byte store (byte stores from 64 lanes
+// use a quarter of a store instruction's width).
 template <typename T>
 __global__ __launch_bounds__(256) void scale_to_u8(const T* __restrict__ src, size_t n, float a, float b,
                                                    const DogScalars* __restrict__ sc, uint8_t* __restrict__ dst)
 {
     bool zero = false;
     if (sc) { a = sc->a8; b = sc->b8; zero = sc->src_max_is_zero != 0; }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v = __fadd_rn(__fmul_rn((float)src[i], a), b);
-        dst[i] = zero ? (uint8_t)0 : (uint8_t)d_clamp(d_cvround(v), 0, 255);
+    auto cvt = [&](float x) -> unsigned {
+        float v = __fadd_rn(__fmul_rn(x, a), b);
+        return zero ? 0u : (unsigned)d_clamp(d_cvround(v), 0, 255);
+    };
+    const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    const bool vec = (((size_t)src & (4 * sizeof(T) - 1)) | ((size_t)dst & 3)) == 0;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t i = tid; i < n4; i += stride) {
+        float x0, x1, x2, x3;
+        if constexpr (sizeof(T) == 4) {
+            const float4 q = reinterpret_cast<const float4*>(src)[i];
+            x0 = q.x; x1 = q.y; x2 = q.z; x3 = q.w;
+        } else {
+            const T* s = src + 4 * i;
+            x0 = (float)s[0]; x1 = (float)s[1]; x2 = (float)s[2]; x3 = (float)s[3];
+        }
+        reinterpret_cast<unsigned*>(dst)[i] = cvt(x0) | (cvt(x1) << 8) | (cvt(x2) << 16) | (cvt(x3) << 24);
     }
+    for (size_t i = n4 * 4 + tid; i < n; i += stride) dst[i] = (uint8_t)cvt((float)src[i]);
 }
 
 template <typename T>

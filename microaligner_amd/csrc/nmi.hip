@@ -65,47 +65,56 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// one block per chunk
-__global__ __launch_bounds__(256) void nmi_reduce_kernel(const unsigned* __restrict__ hist, size_t n, size_t chunk,
-                                                         double* __restrict__ scores)
+// One block of 1024 threads per chunk: thread (q, j) owns column j of the rows [64q, 64q+64) of the chunk's
+// histogram, so the 2 x 65536 double-precision logarithms of a chunk are spread over 16 waves.
+constexpr int NR_T = 1024;
+__global__ __launch_bounds__(NR_T) void nmi_reduce_kernel(const unsigned* __restrict__ hist, size_t n, size_t chunk,
+                                                          double* __restrict__ scores)
 {
-    __shared__ unsigned pa[256];
-    __shared__ unsigned long long pb_s[256];
-    __shared__ double red[4];
+    __shared__ unsigned paq[4][256], pbq[4][256];
+    __shared__ unsigned pa[256], pb[256];
+    __shared__ double red[NR_T / 64];
     __shared__ int cnt[2];
     const unsigned* hh = hist + (size_t)blockIdx.x * 65536;
-    const int j = threadIdx.x, lane = j & 63, w = j >> 6;
+    const int t = threadIdx.x, j = t & 255, q = t >> 8, lane = t & 63, w = t >> 6;
     const size_t c0 = (size_t)blockIdx.x * chunk;
     const double N = (double)((c0 + chunk < n ? c0 + chunk : n) - c0);
 
-    if (j < 2) cnt[j] = 0;
-    // marginals: thread j sums column j (coalesced across the wave) and row j (64 independent 16-byte loads);
-    // all loads are independent, nothing is reduced across lanes
-    unsigned long long pbj = 0;
-#pragma unroll 16
-    for (int r = 0; r < 256; r++) pbj += hh[r * 256 + j];
+    if (t < 2) cnt[t] = 0;
+    // marginals (counts < 2^32 by the chunk limit): column j over this thread's rows (coalesced across the wave)
+    // and a quarter of row j (16 independent 16-byte loads)
     {
-        const uint4* row = reinterpret_cast<const uint4*>(hh + j * 256);
-        unsigned s = 0;
+        unsigned sb = 0;
 #pragma unroll 16
-        for (int q = 0; q < 64; q++) { uint4 v = row[q]; s += v.x + v.y + v.z + v.w; }
-        pa[j] = s;
+        for (int r = 0; r < 64; r++) sb += hh[(64 * q + r) * 256 + j];
+        pbq[q][j] = sb;
+        const uint4* row = reinterpret_cast<const uint4*>(hh + j * 256 + 64 * q);
+        unsigned sa = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { uint4 v = row[k]; sa += v.x + v.y + v.z + v.w; }
+        paq[q][j] = sa;
     }
-    pb_s[j] = pbj;
     __syncthreads();
-    if (pa[j] > 0) atomicAdd(&cnt[0], 1);
-    if (pbj > 0) atomicAdd(&cnt[1], 1);
+    if (q == 0) {
+        const unsigned a = paq[0][j] + paq[1][j] + paq[2][j] + paq[3][j];
+        const unsigned b = pbq[0][j] + pbq[1][j] + pbq[2][j] + pbq[3][j];
+        pa[j] = a; pb[j] = b;
+        if (a > 0) atomicAdd(&cnt[0], 1);
+        if (b > 0) atomicAdd(&cnt[1], 1);
+    }
     __syncthreads();
     const int ca = cnt[0], cb = cnt[1];
     if (ca == 1 && cb == 1) {  // both label sets have a single value
-        if (j == 0) scores[blockIdx.x] = 1.0;
+        if (t == 0) scores[blockIdx.x] = 1.0;
         return;
     }
     const double logN = log(N);
+    const unsigned long long pbj = pb[j];
     double mi = 0.0;
     if (pbj > 0) {
 #pragma unroll 8
-        for (int r = 0; r < 256; r++) {
+        for (int rr = 0; rr < 64; rr++) {
+            const int r = 64 * q + rr;
             unsigned nij = hh[r * 256 + j];
             if (nij) {
                 double log_nm = log((double)nij);
@@ -118,20 +127,23 @@ __global__ __launch_bounds__(256) void nmi_reduce_kernel(const unsigned* __restr
             }
         }
     }
-    // entropies: thread j contributes label j of each side
+    // entropies: thread (0, j) contributes label j of each side
     double ha = 0.0, hb = 0.0;
-    if (pa[j] > 0) ha = ((double)pa[j] / N) * (log((double)pa[j]) - logN);
-    if (pbj > 0) hb = ((double)pbj / N) * (log((double)pbj) - logN);
-
+    if (q == 0) {
+        if (pa[j] > 0) ha = ((double)pa[j] / N) * (log((double)pa[j]) - logN);
+        if (pbj > 0) hb = ((double)pbj / N) * (log((double)pbj) - logN);
+    }
     double vals[3] = {mi, ha, hb}, tot[3];
     for (int k = 0; k < 3; k++) {
         double s = wave_sum(vals[k]);
         if (lane == 0) red[w] = s;
         __syncthreads();
-        tot[k] = red[0] + red[1] + red[2] + red[3];
+        double a = 0.0;
+        for (int i = 0; i < NR_T / 64; i++) a += red[i];
+        tot[k] = a;
         __syncthreads();
     }
-    if (j == 0) {
+    if (t == 0) {
         double m = tot[0] < 0 ? 0.0 : tot[0];
         double score;
         if (fabs(m) < DBL_EPSILON) score = 0.0;
@@ -172,7 +184,7 @@ int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t 
         MA_REQUIRE(slices * 4 <= 0x7fffffff, "chunk too large");
         hipLaunchKernelGGL(joint_hist_kernel, dim3((unsigned)(slices * 4), (unsigned)nchunks), dim3(256), 0, ctx->stream,
                            a, b, n, chunk, hist);
-        hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)nchunks), dim3(256), 0, ctx->stream, hist, n, chunk, scores);
+        hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)nchunks), dim3(NR_T), 0, ctx->stream, hist, n, chunk, scores);
         MA_HIP(hipGetLastError());
     }
     MA_HIP(hipMemcpyAsync(ctx->pinned, scores, nchunks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -171,7 +171,8 @@ def test_merge_two_flows_function(ctx):
 
 
 # ---- pyramids -----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(200, 300), (201, 303), (5, 7), (1, 9), (100, 1)])
+@pytest.mark.parametrize("shape", [(200, 300), (201, 303), (5, 7), (1, 9), (100, 1), (37, 1028), (64, 2052), (9, 8),
+                                   (3, 4)])
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 def test_pyr_down_bit_exact(ctx, shape, dtype):
     rng = np.random.default_rng(shape[0])
@@ -180,7 +181,9 @@ def test_pyr_down_bit_exact(ctx, shape, dtype):
 
 
 @pytest.mark.parametrize("src,dst", [((50, 70), (100, 140)), ((50, 70), (99, 139)), ((51, 33), (102, 65)),
-                                     ((2, 2), (4, 3)), ((105, 101), (210, 202))])
+                                     ((2, 2), (4, 3)), ((105, 101), (210, 202)), ((50, 70), (101, 141)),
+                                     ((40, 600), (80, 1200)), ((33, 515), (65, 1029)), ((1, 5), (2, 10)),
+                                     ((6, 1), (12, 2)), ((3, 3), (7, 7))])
 @pytest.mark.parametrize("scale", [1.0, 2.0, 4.0])
 def test_pyr_up_flow_bit_exact(ctx, src, dst, scale):
     f = rand_flow(src[0], src[1], 11, 5.0)
