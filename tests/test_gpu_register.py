@@ -136,6 +136,55 @@ def test_full_size_properties_4096(ctx):
     assert s.shape == (17,) and np.allclose(s, 1.0, atol=1e-12)
 
 
+def _window(arr, ty, tx, tile, overlap):
+    """The zero-padded window (ty, tx) of `arr` as slicer.py cuts it."""
+    H, W = arr.shape[:2]
+    P = tile + 2 * overlap
+    y0, x0 = ty * tile - overlap, tx * tile - overlap
+    win = np.zeros((P, P) + arr.shape[2:], arr.dtype)
+    ys, xs, ye, xe = max(y0, 0), max(x0, 0), min(y0 + P, H), min(x0 + P, W)
+    win[ys - y0:ye - y0, xs - x0:xe - x0] = arr[ys:ye, xs:xe]
+    return win
+
+
+def test_full_size_16384_windows_match_the_oracle_bit_for_bit(ctx):
+    """BASELINE cfg3 size (16384^2 float32, 17 x 17 windows of 1200^2).  Windows are independent, so the stitched
+    full-size result restricted to one tile must equal the oracle run on that window alone: checked bit for bit on
+    interior, edge and corner windows for the Farneback flow and for the warp, plus determinism of a second run."""
+    H = W = 16384
+    tile, ov = 1000, 100
+    ref, mov = synthetic.make_pair(H, W, 3)
+    dref, dmov = ctx.asdevice(ref), ctx.asdevice(mov)
+    dflow = ctx.farneback(dmov, dref, 99, 3, tile=tile, overlap=ov)
+    flow = dflow.numpy()
+    picks = [(0, 0), (8, 5), (3, 16), (16, 9), (16, 16)]   # corner, interior, right edge, bottom edge, last (384 px valid)
+    prev = np.stack([_window(mov, ty, tx, tile, ov) for ty, tx in picks])
+    nxt = np.stack([_window(ref, ty, tx, tile, ov) for ty, tx in picks])
+    exp = RO.O.farneback_batch(prev, nxt, 99, 3, nthreads=len(picks))
+    for (ty, tx), e in zip(picks, exp):
+        vh, vw = min(tile, H - ty * tile), min(tile, W - tx * tile)
+        got = flow[ty * tile:ty * tile + vh, tx * tile:tx * tile + vw]
+        assert np.array_equal(got, e[ov:ov + vh, ov:ov + vw]), (ty, tx)
+    # warp with the computed flow: same windows, oracle remap of the window
+    warped = ctx.warp(dmov, dflow, tile, ov).numpy()
+    for ty, tx in picks:
+        im, fl = _window(mov, ty, tx, tile, ov), _window(flow, ty, tx, tile, ov)
+        m = np.negative(fl)
+        m[:, :, 0] += np.arange(m.shape[1])
+        m[:, :, 1] += np.arange(m.shape[0]).reshape(-1, 1)
+        e = RO.O.remap(im, m)
+        vh, vw = min(tile, H - ty * tile), min(tile, W - tx * tile)
+        assert np.array_equal(warped[ty * tile:ty * tile + vh, tx * tile:tx * tile + vw], e[ov:ov + vh, ov:ov + vw]), (ty, tx)
+    # determinism
+    assert sha(ctx.farneback(dmov, dref, 99, 3, tile=tile, overlap=ov).numpy()) == sha(flow)
+    # the flow follows the synthetic displacement away from the image border
+    ys, xs = np.arange(6000, 8000, dtype=np.float64)[:, None], np.arange(9000, 11000, dtype=np.float64)[None, :]
+    dx = synthetic.GLOBAL_SHIFT[0] + 2.0 * np.sin(2 * np.pi * ys / H * 3) + 0 * xs   # synthetic.displacement on the block
+    dy = synthetic.GLOBAL_SHIFT[1] + 2.0 * np.cos(2 * np.pi * xs / W * 2) + 0 * ys
+    err = np.abs(flow[6000:8000, 9000:11000] - np.stack([dx, dy], -1))
+    assert err.mean() < 0.3
+
+
 def test_image_too_small_for_any_level_is_a_value_error():
     ref, mov = synthetic.make_pair(150, 150, 1)
     reg = make_reg(dict(num_pyr_lvl=3, use_full_res_img=False))
