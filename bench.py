@@ -99,6 +99,49 @@ def cpu_baseline(sample, params):
                       f"{dt:.1f} s of CPU work"}
 
 
+def lanes_leg(lanes, steps, device, dref, dmov, params, tile, overlap):
+    """Seconds per pair with `lanes` pairs in flight (each lane: own context, `steps` register()+warp() passes)."""
+    import threading
+    from microaligner_amd import OptFlowRegistrator, Warper
+    from microaligner_amd.device import Context, use_context
+    bar, spans = threading.Barrier(lanes), []
+
+    def lane():
+        ctx = Context(device)
+        with use_context(ctx):
+            reg = OptFlowRegistrator()
+            reg.verbose = False
+            for k, v in params.items():
+                setattr(reg, k, v)
+            w = Warper()
+            w.tile_size, w.overlap = tile, overlap
+
+            def one():
+                reg.ref_img, reg.mov_img = dref, dmov   # read-only inputs shared by the lanes
+                flow = reg.register()
+                w.image, w.flow = dmov, flow
+                return w.warp()
+
+            one()
+            ctx.sync()
+            bar.wait()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            ctx.sync()
+            spans.append((t0, time.perf_counter()))
+        ctx.close()
+
+    th = [threading.Thread(target=lane) for _ in range(lanes)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if len(spans) != lanes:
+        raise RuntimeError("a lane failed")
+    return (max(b for _, b in spans) - min(a for a, _ in spans)) / (lanes * steps)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +154,7 @@ def main():
     ap.add_argument("--no-dog", action="store_true", help="experiment: run the workload with use_dog=False")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational FMA-mode leg (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--lanes", type=int, default=3, help="pairs in flight for the informational multi-lane leg (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,6 +262,13 @@ def main():
             reg.muladd_fused = False
             res["variants"] = {"muladd_fma": {"value": round(H * W / tf / 1e6, 2), "unit": "Mpix/s",
                                               "ms_per_step": round(tf * 1e3, 3)}}
+            if args.lanes > 1:
+                # informational: `lanes` independent pairs in flight on this GPU, one context (HIP stream, workspace)
+                # and one host thread per lane -- what parallel.register_pairs(lanes=...) does for a list of pairs
+                tl = lanes_leg(args.lanes, args.steps, ctx.device, dref, dmov, params, reg.tile_size, reg.overlap)
+                res["variants"][f"lanes{args.lanes}"] = {
+                    "value": round(H * W / tl / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(tl * 1e3, 3),
+                    "pairs_in_flight": args.lanes}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample, params)
         print(json.dumps(res))

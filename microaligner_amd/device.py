@@ -6,6 +6,7 @@ stream ordered on the context's stream, so intermediate results never visit the 
 """
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
@@ -311,6 +312,25 @@ class Context:
 
 
 _contexts = {}
+_tls = threading.local()
+
+
+class use_context:
+    """`with use_context(ctx):` makes `ctx` the context get_context() returns on this thread.  Several contexts
+    (each with its own HIP stream, workspace and buffer pool) can drive one device from different threads: that is
+    how independent (ref, mov) pairs are kept in flight together (parallel.register_pairs(lanes=...))."""
+
+    def __init__(self, ctx):
+        self.ctx, self.prev = ctx, None
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "ctx", None)
+        _tls.ctx = self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        _tls.ctx = self.prev
+        return False
 
 
 def default_device():
@@ -325,6 +345,9 @@ def default_device():
 def get_context(device=None):
     """Process-wide context of a device (created on first use).  Raises when no HIP device exists."""
     if device is None:
+        cur = getattr(_tls, "ctx", None)
+        if cur is not None:
+            return cur
         device = default_device()
     ctx = _contexts.get(device)
     if ctx is None:

@@ -232,3 +232,14 @@ def test_page_warp_driver_matches_single_page_warps(ctx):
     assert w.warp_pages([]) == []
     with pytest.raises(ValueError):
         w.warp_pages([pages[0][:10]])
+
+
+def test_register_pairs_with_lanes_matches_single_lane():
+    """Several pairs in flight on one GPU (one context and host thread per lane) give the same bits."""
+    from microaligner_amd import parallel
+    pairs = [synthetic.make_pair(700, 900, seed) for seed in (1, 2, 3, 4, 5)]
+    params = dict(num_pyr_lvl=2, use_full_res_img=True, tile_size=300, overlap=40, use_dog=True)
+    one = parallel.register_pairs(pairs, params, warp=True, lanes=1)
+    many = parallel.register_pairs(pairs, params, warp=True, lanes=3)
+    for (f1, w1), (f3, w3) in zip(one, many):
+        assert np.array_equal(f1, f3) and np.array_equal(w1, w3)

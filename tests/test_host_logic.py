@@ -82,3 +82,39 @@ def test_synthetic_pair_is_seeded_and_displaced():
     _, m1 = synthetic.make_pair(100, 90, 3, band=2048)
     _, m2 = synthetic.make_pair(100, 90, 3, band=17)
     assert np.array_equal(m1, m2)
+
+
+def test_lanes_run_every_unit_once_under_their_own_context(monkeypatch):
+    """parallel.run_sharded(lanes=L): L threads, each with its own context installed as the thread's current one."""
+    import threading
+    from microaligner_amd import device, parallel
+
+    class FakeCtx:
+        made, closed = [], []
+
+        def __init__(self):
+            FakeCtx.made.append(self)
+
+        def close(self):
+            FakeCtx.closed.append(self)
+
+    monkeypatch.setattr(parallel, "_make_lane_context", FakeCtx)
+    seen = {}
+
+    def fn(u):
+        seen[u] = (threading.current_thread().name, device.get_context())
+        return u * u
+
+    out = parallel.run_sharded(list(range(11)), fn, gather=True, lanes=3)
+    assert out == [u * u for u in range(11)]
+    assert len(FakeCtx.made) == 3 and FakeCtx.closed and set(FakeCtx.closed) == set(FakeCtx.made)
+    assert all(name.startswith("ma-lane-") and isinstance(c, FakeCtx) for name, c in seen.values())
+    assert getattr(device._tls, "ctx", None) is None            # nothing leaks onto the calling thread
+
+    def bad(u):
+        if u == 4:
+            raise RuntimeError("boom")
+        return u
+
+    with pytest.raises(RuntimeError, match="boom"):
+        parallel.run_sharded(list(range(8)), bad, lanes=2)
