@@ -136,7 +136,8 @@ int minmax_host(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn, d
 // Block: 256 output columns x DR rows.  The normalised input row segment (+- r halo, reflect-101) is staged in
 // LDS; every thread accumulates both kernels left to right over the ksize taps (one LDS read per tap, shared).
 constexpr int DR = 4;
-template <typename T>
+// KS: compile-time kernel size of the register-window fast path (0: any size, one LDS read per tap)
+template <typename T, int KS>
 __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h, int w, int ksize,
                                                 const DogScalars* __restrict__ sc, const float* __restrict__ klh,
                                                 float* __restrict__ tlo, float* __restrict__ thi)
@@ -157,31 +158,80 @@ __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h
             va[row] = (float)s[xa];
             vb[row] = (float)s[xb];
         }
+        // copy A: lds[row][c] = v[c]; copy B (offset DR * span + 64): the same row shifted by one element,
+        // B[row][c] = v[c + 1], so that the odd-offset input pairs of the row pass are aligned 16-byte reads too
+        float* ldb = lds + DR * span + 64;
 #pragma unroll
         for (int row = 0; row < DR; row++) {
-            lds[row * span + threadIdx.x] = __fadd_rn(__fmul_rn(va[row], a), b);
-            if (c1 < span) lds[row * span + c1] = __fadd_rn(__fmul_rn(vb[row], a), b);
+            const float fa = __fadd_rn(__fmul_rn(va[row], a), b), fb = __fadd_rn(__fmul_rn(vb[row], a), b);
+            lds[row * span + threadIdx.x] = fa;
+            if (threadIdx.x > 0) ldb[row * span + threadIdx.x - 1] = fa;
+            if (c1 < span) { lds[row * span + c1] = fb; ldb[row * span + c1 - 1] = fb; }
         }
     }
     __syncthreads();
-    const int x = x0 + threadIdx.x;
-    if (x >= w) return;
-    // both sigmas as one register pair: klh[j] = (k_lo[j], k_hi[j]); acc = acc + k * v per component, left to right
-    const ma_f2* __restrict__ kk = reinterpret_cast<const ma_f2*>(klh);
+    // A thread produces 4 consecutive columns of ONE row (wave = row) as two register pairs per sigma,
+    // (out0, out1) and (out2, out3).  Its ksize + 3 inputs come from LDS as 16-byte reads, once as the aligned
+    // pairs E[q] = (v[2q], v[2q+1]) and once, from the shifted copy, as O[q] = (v[2q+1], v[2q+2]): tap j multiplies
+    // the pair starting at v[j] (E or O by parity) by the tap broadcast from an SGPR -- packed math with no
+    // register shuffles, 2 packed ops per output and tap, and a quarter of the LDS instructions of one read per
+    // tap.  Per output: acc = k0*v0, then acc = acc + k_j*v_j for ascending j, exactly the scalar order.
+    const int row = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int y = y0 + row, x = x0 + 4 * lane;
+    if (y >= h || x >= w) return;
+    const ma_f2* __restrict__ kk = reinterpret_cast<const ma_f2*>(klh);   // klh[j] = (k_lo[j], k_hi[j])
+    ma_f2 acc[4];
+    if constexpr (KS > 0) {
+        constexpr int KMAX = (KS + 3 + 3) / 4 * 4;  // inputs per thread, rounded up to whole 16-byte reads
+        ma_f2 E[KMAX / 2], O[KMAX / 2];
+        const float4* a4 = reinterpret_cast<const float4*>(lds + row * span + 4 * lane);
+        const float4* b4 = reinterpret_cast<const float4*>(lds + DR * span + 64 + row * span + 4 * lane);
 #pragma unroll
-    for (int row = 0; row < DR; row++) {
-        const int y = y0 + row;
-        if (y >= h) break;
-        const float* v = lds + row * span + threadIdx.x;
-        ma_f2 acc = kk[0] * (ma_f2){v[0], v[0]};
-#pragma unroll 8
-        for (int j = 1; j < ksize; j++) {
-            const float vj = v[j];
-            const ma_f2 p = kk[j] * (ma_f2){vj, vj};
-            acc = acc + p;
+        for (int q = 0; q < KMAX / 4; q++) {
+            // reads past ksize + 3 stay inside the block's LDS allocation (next row or tail pad) and are not used
+            const float4 t = a4[q], u = b4[q];
+            E[2 * q] = (ma_f2){t.x, t.y}; E[2 * q + 1] = (ma_f2){t.z, t.w};
+            O[2 * q] = (ma_f2){u.x, u.y}; O[2 * q + 1] = (ma_f2){u.z, u.w};
         }
-        tlo[(size_t)y * w + x] = acc.x;
-        thi[(size_t)y * w + x] = acc.y;
+        ma_f2 lo01, lo23, hi01, hi23;
+        {
+            const ma_f2 k = kk[0];
+            const ma_f2 kl = {k.x, k.x}, kh = {k.y, k.y};
+            lo01 = E[0] * kl; lo23 = E[1] * kl; hi01 = E[0] * kh; hi23 = E[1] * kh;
+        }
+#pragma unroll
+        for (int j = 1; j < KS; j++) {
+            const ma_f2 k = kk[j];
+            const ma_f2 kl = {k.x, k.x}, kh = {k.y, k.y};
+            const ma_f2 d01 = (j & 1) ? O[(j - 1) / 2] : E[j / 2];
+            const ma_f2 d23 = (j & 1) ? O[(j - 1) / 2 + 1] : E[j / 2 + 1];
+            lo01 = lo01 + d01 * kl; lo23 = lo23 + d23 * kl;
+            hi01 = hi01 + d01 * kh; hi23 = hi23 + d23 * kh;
+        }
+        acc[0] = (ma_f2){lo01.x, hi01.x}; acc[1] = (ma_f2){lo01.y, hi01.y};
+        acc[2] = (ma_f2){lo23.x, hi23.x}; acc[3] = (ma_f2){lo23.y, hi23.y};
+    } else {
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const float* v = lds + row * span + 4 * lane + o;   // columns past the image stay inside the staged span
+            ma_f2 s2 = kk[0] * (ma_f2){v[0], v[0]};
+            for (int j = 1; j < ksize; j++) {
+                const float vj = v[j];
+                const ma_f2 p = kk[j] * (ma_f2){vj, vj};
+                s2 = s2 + p;
+            }
+            acc[o] = s2;
+        }
+    }
+    float* plo = tlo + (size_t)y * w + x;
+    float* phi = thi + (size_t)y * w + x;
+    if (x + 3 < w && (w & 3) == 0) {
+        *reinterpret_cast<float4*>(plo) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
+        *reinterpret_cast<float4*>(phi) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
+    } else {
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+            if (x + o < w) { plo[o] = acc[o].x; phi[o] = acc[o].y; }
     }
 }
 
@@ -346,7 +396,7 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     const size_t n = (size_t)h * w;
     const int ksize = low_sigma * 4 * 2 + 1;  // optflow_registrator.py:262
     const int r = ksize / 2;
-    const size_t lds_rows = (size_t)DR * (256 + 2 * r) * sizeof(float);
+    const size_t lds_rows = 2 * ((size_t)DR * (256 + 2 * r) + 64) * sizeof(float);  // two copies (+ tail pad for the 16-byte reads)
     const int DC_R = (r % 10 == 0) ? 20 : 16;
     const size_t lds_cols = (size_t)(DC_NW * DC_R + 2 * r + 4) * 64 * sizeof(float);
     MA_REQUIRE(lds_rows <= 160 * 1024 && lds_cols <= 160 * 1024, "low_sigma too large for the LDS-staged DOG kernels");
@@ -384,9 +434,17 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc);
     {
         dim3 grid((w + 255) / 256, (h + DR - 1) / DR), block(256);
-        if (dtype == MA_U8) hipLaunchKernelGGL((dog_rows<uint8_t>), grid, block, lds_rows, ctx->stream, (const uint8_t*)src, h, w, ksize, sc, dlo, tlo, thi);
-        else if (dtype == MA_U16) hipLaunchKernelGGL((dog_rows<uint16_t>), grid, block, lds_rows, ctx->stream, (const uint16_t*)src, h, w, ksize, sc, dlo, tlo, thi);
-        else hipLaunchKernelGGL((dog_rows<float>), grid, block, lds_rows, ctx->stream, (const float*)src, h, w, ksize, sc, dlo, tlo, thi);
+#define MA_DOG_ROWS(T, KS) hipLaunchKernelGGL((dog_rows<T, KS>), grid, block, lds_rows, ctx->stream, (const T*)src, h, w, ksize, sc, dlo, tlo, thi)
+        if (ksize == 41) {  // the reference's sigmas (5, 9): register-window path
+            if (dtype == MA_U8) MA_DOG_ROWS(uint8_t, 41);
+            else if (dtype == MA_U16) MA_DOG_ROWS(uint16_t, 41);
+            else MA_DOG_ROWS(float, 41);
+        } else {
+            if (dtype == MA_U8) MA_DOG_ROWS(uint8_t, 0);
+            else if (dtype == MA_U16) MA_DOG_ROWS(uint16_t, 0);
+            else MA_DOG_ROWS(float, 0);
+        }
+#undef MA_DOG_ROWS
     }
     if (DC_R == 20)
         hipLaunchKernelGGL((dog_cols_diff<20, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,

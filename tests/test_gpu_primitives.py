@@ -208,6 +208,21 @@ def test_dog_bit_exact(ctx, dtype, shape):
     assert got.dtype == np.uint8 and np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("sigmas", [(1, 2), (3, 5), (6, 9)])
+def test_dog_other_sigmas_bit_exact(ctx, sigmas):
+    """Kernel sizes other than the reference's 41 (generic row pass, column pass with tail taps)."""
+    img, _ = pair(150, 333, seed=4)
+    exp = O.dog(img, True, *sigmas)
+    assert np.array_equal(ctx.dog_u8(ctx.asdevice(img), *sigmas).numpy(), exp)
+
+
+@pytest.mark.parametrize("shape", [(70, 1030), (33, 1024), (9, 517)])
+def test_dog_wide_rows_bit_exact(ctx, shape):
+    """Several 256-column blocks per row, widths that are and are not multiples of 4."""
+    img, _ = pair(*shape, seed=shape[1])
+    assert np.array_equal(ctx.dog_u8(ctx.asdevice(img)).numpy(), O.dog(img, True))
+
+
 def test_dog_special_cases_and_minmax(ctx):
     from microaligner_amd import OptFlowRegistrator
     reg = OptFlowRegistrator()
