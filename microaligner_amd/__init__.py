@@ -8,8 +8,8 @@ Compute runs in hand-written HIP kernels for gfx950 behind a C-ABI (include/micr
 there is no CPU fallback.
 """
 from .optflow_reg import OptFlowRegistrator, TileFlowCalc, Warper, farneback, merge_two_flows
-from .shared_modules.utils import pad_to_shape, transform_img_with_tmat
+from .shared_modules.utils import max_project_and_normalize, pad_to_shape, transform_img_with_tmat
 
 __all__ = ["OptFlowRegistrator", "Warper", "TileFlowCalc", "farneback", "merge_two_flows", "pad_to_shape",
-           "transform_img_with_tmat"]
+           "transform_img_with_tmat", "max_project_and_normalize"]
 __version__ = "0.1.0"

@@ -153,3 +153,50 @@ def warp_pages(pages: Sequence, flow, tile_size: int = 1000, overlap: int = 100,
     for part in bucket:
         merged.update(part)
     return [merged[i] for i in range(len(pages))]
+
+
+def register_cycle_chain(cycles: Sequence, ref_channel_ids=None, params: Optional[dict] = None):
+    """The optical-flow cycle loop of the reference pipeline on in-memory stacks (__main__.py:398-433).
+
+    cycles: sequence of (C, Z, H, W) arrays, one per cycle, first = reference cycle.  For every later cycle the
+    max-projected, uint8-normalised reference channel (utils.py:75-95) is registered against the *previous cycle's
+    warped* reference image (the chain of :418-424), and every channel x z page of the cycle is warped with that
+    one flow (warp_and_save_pages, :288-302) -- flow resident in HBM, page transfers overlapped.
+    Returns (aligned cycles as arrays of the input shape and dtype, flows as numpy arrays; flows[0] is None).
+    The chain is serial across cycles; run it on one rank (pages of a cycle can be sharded with warp_pages)."""
+    import numpy as np
+    from . import OptFlowRegistrator, Warper
+    from .shared_modules.utils import max_project_and_normalize
+    params = dict(params or {})
+    ref_channel_ids = list(ref_channel_ids) if ref_channel_ids is not None else [0] * len(cycles)
+    if len(ref_channel_ids) != len(cycles):
+        raise ValueError("one reference channel id per cycle is required")
+    aligned, flows, ref_img = [], [], None
+    for cyc, stack in enumerate(cycles):
+        stack = np.asarray(stack)
+        if stack.ndim != 4:
+            raise ValueError(f"cycle {cyc}: expected a (C, Z, H, W) stack, got shape {stack.shape}")
+        C_, Z_, H, W = stack.shape
+        mov_img = max_project_and_normalize(stack[ref_channel_ids[cyc]], on_device=True)
+        if cyc == 0:
+            ref_img = mov_img                       # "Skipping as it is a reference image" (:411-413)
+            aligned.append(stack.copy())
+            flows.append(None)
+            continue
+        reg = OptFlowRegistrator()
+        reg.verbose = False
+        for k, v in params.items():
+            setattr(reg, k, v)
+        reg.ref_img, reg.mov_img = ref_img, mov_img
+        flow = reg.register()
+        w = Warper()
+        w.tile_size, w.overlap = reg.tile_size, reg.overlap
+        w.image, w.flow = mov_img, flow
+        ref_img = w.warp()                          # reference of the next cycle (:424)
+        w.flow = flow
+        out = np.empty_like(stack)
+        w.warp_pages([stack[c, z] for c in range(C_) for z in range(Z_)],
+                     out=[out[c, z] for c in range(C_) for z in range(Z_)])
+        aligned.append(out)
+        flows.append(flow.numpy())
+    return aligned, flows

@@ -39,3 +39,21 @@ def transform_img_with_tmat(img, target_shape: Tuple[int, int], transform_matrix
     ctx = get_context()
     out = ctx.warp_affine(ctx.asdevice(np.ascontiguousarray(img)), inv)
     return out.numpy().astype(original_dtype, copy=False)
+
+
+def max_project_and_normalize(pages, on_device: bool = False):
+    """In-memory counterpart of read_and_max_project_pages (utils.py:75-95): element-wise maximum over the z pages
+    (np.maximum fold, :92) followed by cv2.normalize(..., 0, 255, NORM_MINMAX, CV_8U) (:94), both on the device.
+    `pages`: a (Z, H, W) array or a sequence of (H, W) pages (uint8 / uint16 / float32).  Returns uint8."""
+    from ..device import DeviceArray, get_context
+    ctx = get_context()
+    if isinstance(pages, DeviceArray):
+        stack = pages
+    else:
+        stack = ctx.asdevice(np.ascontiguousarray(np.stack([np.asarray(p) for p in pages])))
+    if stack.ndim != 3:
+        raise ValueError(f"expected (Z, H, W) pages, got shape {stack.shape}")
+    proj = ctx.max_project(stack) if stack.shape[0] > 1 else DeviceArray(ctx, stack.shape[1:], stack.dtype, stack.ptr, 0, owner=False)
+    out = ctx.normalize_minmax_u8(proj)
+    del proj
+    return out if on_device else out.numpy()

@@ -243,3 +243,38 @@ def test_register_pairs_with_lanes_matches_single_lane():
     many = parallel.register_pairs(pairs, params, warp=True, lanes=3)
     for (f1, w1), (f3, w3) in zip(one, many):
         assert np.array_equal(f1, f3) and np.array_equal(w1, w3)
+
+
+def test_cycle_chain_matches_the_oracle_pipeline():
+    """BASELINE cfg4 in miniature: TCZYX cycles, z max-projection + uint8 normalisation of the reference channel,
+    the chained registration (each cycle against the previous warped one) and the page warps, against the same
+    pipeline composed from the oracle (numpy maximum, oracle normalize / register / warp)."""
+    from oracle import oracle as O
+    from microaligner_amd import parallel
+    rng = np.random.default_rng(5)
+    H, W, C_, Z_ = 420, 510, 2, 3
+    base, _ = synthetic.make_pair(H + 40, W + 40, 9)
+    cycles = []
+    for cyc in range(3):
+        dy, dx = 3 * cyc, 2 * cyc                   # every cycle drifts a little further
+        stack = np.empty((C_, Z_, H, W), np.uint16)
+        for c in range(C_):
+            for z in range(Z_):
+                img = base[20 + dy:20 + dy + H, 20 + dx:20 + dx + W] * (40.0 + 10 * c) * (1.0 - 0.2 * z)
+                stack[c, z] = np.clip(img + rng.normal(0, 20, (H, W)), 0, 65535).astype(np.uint16)
+        cycles.append(stack)
+    params = dict(num_pyr_lvl=2, use_full_res_img=True, tile_size=200, overlap=30, use_dog=True)
+    aligned, flows = parallel.register_cycle_chain(cycles, ref_channel_ids=[1, 1, 1], params=params)
+
+    def conditioned(stack):
+        return O.normalize_minmax_u8(np.maximum.reduce(list(stack[1])).astype(np.float32))
+    ref = conditioned(cycles[0])
+    assert np.array_equal(aligned[0], cycles[0]) and flows[0] is None
+    for cyc in (1, 2):
+        mov = conditioned(cycles[cyc])
+        flow, _ = RO.register(ref, mov, **params)
+        assert np.array_equal(flows[cyc], flow)
+        ref = RO.warp(mov, flow, 200, 30)
+        for c in range(C_):
+            for z in range(Z_):
+                assert np.array_equal(aligned[cyc][c, z], RO.warp(cycles[cyc][c, z], flow, 200, 30))
