@@ -183,6 +183,13 @@ int ma_normalize_minmax_u8(ma_ctx* ctx, const void* src, int dtype, size_t n, ui
 int ma_warp_affine(ma_ctx* ctx, const void* src, int dtype, int h, int w, const double* inverse_3x3_host,
                    void* dst);
 
+/* cv2.warpAffine(src, M, dsize=(dw, dh)) with the default flags (INTER_LINEAR, BORDER_CONSTANT 0), the call of
+ * FeatureRegistrator.transform_img (feature_reg/feature_registrator.py:128-132) for images up to 32000 px.
+ * m2x3_host: the FORWARD 2x3 matrix (6 doubles, row major) exactly as passed to cv2.warpAffine; it is inverted in
+ * double and evaluated in OpenCV's 10-bit fixed point (WarpAffineInvoker), then sampled like cv2.remap. */
+int ma_warp_affine_cv(ma_ctx* ctx, const void* src, int dtype, int sh, int sw, const double* m2x3_host, int dh, int dw,
+                      void* dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,9 +7,10 @@ mirrors `from microaligner import OptFlowRegistrator, Warper` (microaligner/__in
 Compute runs in hand-written HIP kernels for gfx950 behind a C-ABI (include/microaligner_hip.h);
 there is no CPU fallback.
 """
+from .feature_reg import FeatureRegistrator
 from .optflow_reg import OptFlowRegistrator, TileFlowCalc, Warper, farneback, merge_two_flows
 from .shared_modules.utils import max_project_and_normalize, pad_to_shape, transform_img_with_tmat
 
-__all__ = ["OptFlowRegistrator", "Warper", "TileFlowCalc", "farneback", "merge_two_flows", "pad_to_shape",
+__all__ = ["FeatureRegistrator", "OptFlowRegistrator", "Warper", "TileFlowCalc", "farneback", "merge_two_flows", "pad_to_shape",
            "transform_img_with_tmat", "max_project_and_normalize"]
 __version__ = "0.1.0"

@@ -6,6 +6,7 @@
 // HBM-bound gathers: one destination pixel per thread, rows coalesced along x.
 #include "ma_internal.h"
 
+#include <climits>
 #include <cstring>
 
 namespace {
@@ -97,6 +98,39 @@ __global__ __launch_bounds__(256) void remap_kernel(const T* __restrict__ src, i
     }
 #pragma unroll
     for (int k = 0; k < CN; k++) dst[((size_t)y * dw + x) * CN + k] = out[k];
+}
+
+// ---- cv2.warpAffine(src, M, dsize), INTER_LINEAR, BORDER_CONSTANT 0 (feature_registrator.py:130) ----------
+// WarpAffineInvoker's coordinates: 10-bit fixed point, adelta/bdelta per column, X0/Y0 per row (+16 = half of
+// 1/32 px), then >> 5 leaves 5 fractional bits for the bilinear tables shared with remap.  Mi: the INVERTED matrix.
+struct AffineCv { double m[6]; };
+__device__ __forceinline__ int d_sat_int(double v)
+{
+    if (!(v > -2147483648.0)) return INT_MIN;
+    if (!(v < 2147483647.0)) return INT_MAX;
+    return __double2int_rn(v);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void warp_affine_cv_kernel(const T* __restrict__ src, int sh, int sw, AffineCv Mi,
+                                                             int dh, int dw, T* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw) return;
+    const int X0 = d_sat_int((Mi.m[1] * y + Mi.m[2]) * 1024.0) + 16, Y0 = d_sat_int((Mi.m[4] * y + Mi.m[5]) * 1024.0) + 16;
+    const int X = (X0 + d_sat_int(Mi.m[0] * x * 1024.0)) >> 5, Y = (Y0 + d_sat_int(Mi.m[3] * x * 1024.0)) >> 5;
+    Tap t;
+    t.fx = X & 31; t.fy = Y & 31;
+    t.sx = d_sat_short(X >> 5); t.sy = d_sat_short(Y >> 5);
+    T out = 0;
+    if (!(t.sx >= sw || t.sx + 1 < 0 || t.sy >= sh || t.sy + 1 < 0)) {
+        const bool x0 = t.sx >= 0, x1 = t.sx + 1 < sw, y0 = t.sy >= 0, y1 = t.sy + 1 < sh;
+        T v0 = (x0 && y0) ? src[(size_t)t.sy * sw + t.sx] : (T)0;
+        T v1 = (x1 && y0) ? src[(size_t)t.sy * sw + t.sx + 1] : (T)0;
+        T v2 = (x0 && y1) ? src[(size_t)(t.sy + 1) * sw + t.sx] : (T)0;
+        T v3 = (x1 && y1) ? src[(size_t)(t.sy + 1) * sw + t.sx + 1] : (T)0;
+        out = Interp<T>::run(v0, v1, v2, v3, t.fx, t.fy);
+    }
+    dst[(size_t)y * dw + x] = out;
 }
 
 // ---- Warper.warp(): window-local map = float(x_local) - flow, window-local constant border ----
@@ -235,6 +269,35 @@ int ma_remap_bilinear(ma_ctx* ctx, const void* src, int dtype, int cn, int sh, i
     else if (dtype == MA_U16) { if (cn == 1) LAUNCH(uint16_t, 1); else LAUNCH(uint16_t, 2); }
     else { if (cn == 1) LAUNCH(float, 1); else LAUNCH(float, 2); }
 #undef LAUNCH
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+int ma_warp_affine_cv(ma_ctx* ctx, const void* src, int dtype, int sh, int sw, const double* m2x3_host, int dh, int dw,
+                      void* dst)
+{
+    MA_REQUIRE(ctx && src && m2x3_host && dst, "NULL argument");
+    MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
+    MA_REQUIRE(sh > 0 && sw > 0 && dh > 0 && dw > 0 && dh <= 65535, "bad image size");
+    MA_HIP(hipSetDevice(ctx->device));
+    // cv::warpAffine inverts the forward matrix in double before the fixed-point stage
+    AffineCv A;
+    double M[6];
+    for (int i = 0; i < 6; i++) M[i] = m2x3_host[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D;
+    M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5];
+    const double b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    for (int i = 0; i < 6; i++) A.m[i] = M[i];
+    MaProfScope ps(ctx, MA_K_WARP, (double)dh * dw);
+    dim3 grid((dw + 255) / 256, dh), block(256);
+    if (dtype == MA_U8) hipLaunchKernelGGL((warp_affine_cv_kernel<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)src, sh, sw, A, dh, dw, (uint8_t*)dst);
+    else if (dtype == MA_U16) hipLaunchKernelGGL((warp_affine_cv_kernel<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)src, sh, sw, A, dh, dw, (uint16_t*)dst);
+    else hipLaunchKernelGGL((warp_affine_cv_kernel<float>), grid, block, 0, ctx->stream, (const float*)src, sh, sw, A, dh, dw, (float*)dst);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }

@@ -305,6 +305,18 @@ class Context:
         L.check(self.lib.ma_warp_affine(self.handle, img.ptr, _dt(img.dtype), h, w, m, out.ptr))
         return out
 
+    def warp_affine_cv(self, img, m2x3, dsize=None):
+        """cv2.warpAffine(img, m2x3, dsize=(W, H)) with the default flags (bilinear, constant border 0)."""
+        h, w = img.shape
+        dw, dh = (w, h) if dsize is None else (int(dsize[0]), int(dsize[1]))
+        m = np.asarray(m2x3, dtype=np.float64)
+        if m.shape != (2, 3):
+            raise ValueError("the transform must be a 2x3 matrix")
+        mm = (C.c_double * 6)(*[float(v) for v in m.ravel()])
+        out = self.empty((dh, dw), img.dtype)
+        L.check(self.lib.ma_warp_affine_cv(self.handle, img.ptr, _dt(img.dtype), h, w, mm, dh, dw, out.ptr))
+        return out
+
     def normalize_minmax_u8(self, arr):
         out = self.empty(arr.shape, np.uint8)
         L.check(self.lib.ma_normalize_minmax_u8(self.handle, arr.ptr, _dt(arr.dtype), arr.size, out.ptr))

@@ -1,0 +1,85 @@
+"""Keypoints, descriptors and their matching for FeatureRegistrator.
+
+Counterpart of microaligner/feature_reg/feature_detection.py (Features :27-85, find_features :88-120,
+match_features :123-158, find_features_parallelized :161-168).  The reference gets FAST, DAISY, FLANN and the
+RANSAC similarity fit from opencv-contrib; here they come from sparse_cpu.py (see its header for what is and is not
+the same).  Tiles are processed by a thread pool instead of dask.
+"""
+from concurrent.futures import ThreadPoolExecutor
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .sparse_cpu import Daisy, KeyPoint, estimate_affine_partial_2d, fast_detect, knn2
+
+TILE_OVERLAP = 51            # overlap of the feature tiles (tile_registration.py:31) and the margin FAST skips
+RATIO = 0.5                  # Lowe's ratio (feature_detection.py:143)
+
+
+class Features:
+    """Keypoints + descriptors of one image (or tile).  `keypoints` is a list of KeyPoint (pt, size, angle,
+    response, octave, class_id -- the cv2.KeyPoint fields the reference serialises) or None."""
+
+    def __init__(self):
+        self.keypoints: Optional[List[KeyPoint]] = None
+        self.descriptors: Optional[np.ndarray] = None
+
+    def is_valid(self) -> bool:
+        return self.keypoints is not None and self.descriptors is not None
+
+
+def view_tile_without_overlap(img, overlap):
+    return img[overlap:-overlap, overlap:-overlap]
+
+
+def find_features(img: np.ndarray, nfeatures_limit: int = 5000) -> Features:
+    """feature_detection.py:88-120.  FAST corners of the tile's interior (the overlap margin is cut off first, so
+    keypoint coordinates are relative to the interior), strongest `nfeatures_limit` first, DAISY descriptors
+    computed on the FULL tile at those coordinates -- i.e. 51 px up-left of the corner, the reference's own
+    convention (:105 vs :107), kept because reference and moving image are treated alike."""
+    img = np.asarray(img)
+    features = Features()
+    if img.size == 0 or img.max() == 0:
+        return features
+    kp = fast_detect(view_tile_without_overlap(img, TILE_OVERLAP), threshold=1, nonmax=True)
+    kp = sorted(kp, key=lambda k: k.response, reverse=True)[:nfeatures_limit]
+    des = Daisy(radius=21, q_radius=3, q_theta=8, q_hist=8).compute(img, kp)
+    if len(kp) < 3 or des is None or len(des) < 3:
+        return features
+    features.keypoints, features.descriptors = kp, des
+    return features
+
+
+def match_features(img1_features: Features, img2_features: Features, verbose: bool = True) -> np.ndarray:
+    """feature_detection.py:123-158: 2-NN of every descriptor of image 2 among those of image 1, ratio test, then
+    the similarity transform that maps image-2 points onto image-1 points.  Identity when there is too little to
+    go on; None (as cv2 does) when the fit itself fails is mapped to identity as well."""
+    identity = np.eye(2, 3)
+    if not img1_features.is_valid() or not img2_features.is_valid():
+        return identity
+    kp1, des1 = img1_features.keypoints, img1_features.descriptors
+    kp2, des2 = img2_features.keypoints, img2_features.descriptors
+    if len(des1) < 2:
+        return identity
+    idx, dist = knn2(des2, des1)
+    good = np.nonzero(dist[:, 0] < RATIO * dist[:, 1])[0]
+    if verbose:
+        print("    Good matches", len(good), "/", len(des2))
+    if len(good) < 3:
+        return identity
+    src_pts = np.array([kp1[i].pt for i in idx[good, 0]], np.float32)
+    dst_pts = np.array([kp2[i].pt for i in good], np.float32)
+    mat, _ = estimate_affine_partial_2d(dst_pts, src_pts, confidence=0.99)
+    return identity if mat is None else mat
+
+
+def find_features_parallelized(tile_list: Sequence[np.ndarray], workers: int = 8) -> List[Features]:
+    """feature_detection.py:161-168: at most 1 000 000 features over all tiles, at most 5000 per tile."""
+    n_tiles = len(tile_list)
+    if n_tiles == 0:
+        return []
+    limit = min(1000000 // n_tiles, 5000)
+    if n_tiles == 1:
+        return [find_features(tile_list[0], limit)]
+    with ThreadPoolExecutor(max_workers=min(workers, n_tiles)) as ex:
+        return list(ex.map(lambda t: find_features(t, limit), tile_list))

@@ -1,0 +1,220 @@
+"""CPU implementation of the sparse half of FeatureRegistrator: FAST-9/16 corners, DAISY
+descriptors, 2-nearest-neighbour matching with the ratio test and a RANSAC partial-affine fit.
+
+The reference obtains these from opencv-contrib (feature_reg/feature_detection.py:88-158):
+cv.FastFeatureDetector_create(threshold=1, nonmaxSuppression=True, TYPE_9_16), cv.xfeatures2d.DAISY_create(radius=21,
+q_radius=3, q_theta=8, q_hist=8, NRM_NONE, interpolation=True, use_orientation=False), cv.FlannBasedMatcher +
+Lowe's ratio 0.5, cv.estimateAffinePartial2D(RANSAC, confidence=0.99).  opencv-contrib is not available to this
+build, so the stage is restated here from the published algorithms.  It is a sparse, irregular CPU workload (a few
+thousand points per tile), deliberately NOT on the GPU; the dense pieces around it (DOG, pyramids, warpAffine, the
+NMI gate) are.  PARITY UNPINNED: FAST follows OpenCV's segment test, score and 3x3 non-maximum suppression exactly
+as published; DAISY follows Tola et al. (PAMI 2010) with OpenCV's parameter meaning but not its exact smoothing
+schedule; matching is exact 2-NN where FLANN is approximate; RANSAC uses its own random sequence.  The outputs are
+therefore functionally equivalent (same kind of keypoints, descriptors and 2x3 similarity transform), not
+bit-identical to opencv-contrib.
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+# Bresenham circle of radius 3, OpenCV's order (dx, dy)
+_RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
+         (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+@dataclass
+class KeyPoint:
+    """The fields of cv2.KeyPoint that the reference carries around (feature_detection.py:38-71)."""
+    pt: Tuple[float, float]
+    size: float = 7.0
+    angle: float = -1.0
+    response: float = 0.0
+    octave: int = 0
+    class_id: int = -1
+
+
+def fast_score_map(img: np.ndarray, threshold: int = 1) -> np.ndarray:
+    """Corner score of every pixel (0 where the 9-of-16 segment test fails), OpenCV's cornerScore<16>:
+    the largest t for which the pixel is still a corner, i.e. max over the 16 arcs of 9 contiguous ring pixels of
+    min(v - ring) (darker arc) or min(ring - v) (brighter arc), minus 1.  A pixel is a corner iff that maximum
+    exceeds `threshold`.  The 3-pixel border is never a corner."""
+    img = np.asarray(img)
+    if img.dtype != np.uint8:
+        raise ValueError("FAST works on uint8 images (the DOG output)")
+    h, w = img.shape
+    score = np.zeros((h, w), np.int32)
+    if h < 7 or w < 7:
+        return score
+    c = img[3:h - 3, 3:w - 3].astype(np.int16)
+    d = np.empty((16,) + c.shape, np.int16)
+    for k, (dx, dy) in enumerate(_RING):
+        d[k] = c - img[3 + dy:h - 3 + dy, 3 + dx:w - 3 + dx]
+    # circular sliding minimum / maximum over 9 consecutive ring positions by doubling (2, 4, 8, then 9)
+    def windows(op):
+        m2 = [op(d[s], d[(s + 1) % 16]) for s in range(16)]
+        m4 = [op(m2[s], m2[(s + 2) % 16]) for s in range(16)]
+        m8 = [op(m4[s], m4[(s + 4) % 16]) for s in range(16)]
+        return [op(m8[s], d[(s + 8) % 16]) for s in range(16)]
+    best = None
+    for m in windows(np.minimum):          # darker arcs: all (v - ring) large
+        best = m if best is None else np.maximum(best, m)
+    for m in windows(np.maximum):          # brighter arcs: all (ring - v) large  ==  -(max of v - ring)
+        best = np.maximum(best, -m)
+    inner = np.where(best > threshold, best.astype(np.int32) - 1, 0)
+    score[3:h - 3, 3:w - 3] = inner
+    return score
+
+
+def fast_detect(img: np.ndarray, threshold: int = 1, nonmax: bool = True) -> List[KeyPoint]:
+    """cv.FastFeatureDetector_create(threshold, nonmaxSuppression, TYPE_9_16).detect(img): keypoints in row-major
+    order, response = corner score, size 7.  With nonmax a corner survives iff its score is strictly greater than
+    the scores of its 8 neighbours (non-corners count as 0)."""
+    s = fast_score_map(img, threshold)
+    ok = s > 0
+    if nonmax:
+        p = np.pad(s, 1)
+        h, w = s.shape
+        for dy in (-1, 0, 1):
+            for dx in (-1, 0, 1):
+                if dx or dy:
+                    ok &= s > p[1 + dy:1 + dy + h, 1 + dx:1 + dx + w]
+    ys, xs = np.nonzero(ok)
+    return [KeyPoint((float(x), float(y)), 7.0, -1.0, float(s[y, x]), 0, -1) for y, x in zip(ys, xs)]
+
+
+class Daisy:
+    """DAISY descriptor (Tola, Lepetit, Fua 2010) at given points: 1 + q_radius * q_theta histograms of q_hist
+    orientation bins = 200 floats with the reference's parameters, no normalisation (NRM_NONE), bilinear sampling
+    (interpolation=True), fixed orientation (use_orientation=False)."""
+
+    def __init__(self, radius=21, q_radius=3, q_theta=8, q_hist=8):
+        self.radius, self.q_radius, self.q_theta, self.q_hist = radius, q_radius, q_theta, q_hist
+
+    def _cubes(self, img: np.ndarray) -> List[np.ndarray]:
+        from scipy.ndimage import gaussian_filter
+        f = img.astype(np.float32) / (255.0 if img.dtype == np.uint8 else 1.0)
+        gy, gx = np.gradient(f)
+        layers = np.empty((self.q_hist,) + f.shape, np.float32)
+        for o in range(self.q_hist):
+            th = 2.0 * np.pi * o / self.q_hist
+            np.maximum(np.cos(th) * gx + np.sin(th) * gy, 0, out=layers[o])
+        sigmas = [self.radius * (r + 1) / (2.0 * self.q_radius) for r in range(self.q_radius)]
+        cubes, prev, cur = [], 0.0, layers
+        for s in sigmas:
+            inc = float(np.sqrt(s * s - prev * prev))
+            cur = gaussian_filter(cur, sigma=(0, inc, inc), mode="nearest", truncate=3.0)
+            cubes.append(cur)
+            prev = s
+        return cubes
+
+    @staticmethod
+    def _sample(cube: np.ndarray, ys: np.ndarray, xs: np.ndarray) -> np.ndarray:
+        """Bilinear sample of every layer at (ys, xs) (clamped to the image): (n, q_hist)."""
+        _, h, w = cube.shape
+        ys = np.clip(ys, 0, h - 1.0)
+        xs = np.clip(xs, 0, w - 1.0)
+        y0 = np.minimum(np.floor(ys).astype(np.int64), h - 2) if h > 1 else np.zeros(ys.shape, np.int64)
+        x0 = np.minimum(np.floor(xs).astype(np.int64), w - 2) if w > 1 else np.zeros(xs.shape, np.int64)
+        fy = (ys - y0).astype(np.float32)
+        fx = (xs - x0).astype(np.float32)
+        y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+        v = (cube[:, y0, x0] * ((1 - fy) * (1 - fx)) + cube[:, y0, x1] * ((1 - fy) * fx) +
+             cube[:, y1, x0] * (fy * (1 - fx)) + cube[:, y1, x1] * (fy * fx))
+        return v.T
+
+    def compute(self, img: np.ndarray, keypoints: List[KeyPoint]) -> Optional[np.ndarray]:
+        if not keypoints:
+            return None
+        cubes = self._cubes(img)
+        pts = np.array([kp.pt for kp in keypoints], np.float64)
+        xs, ys = pts[:, 0], pts[:, 1]
+        n = len(keypoints)
+        des = np.empty((n, (1 + self.q_radius * self.q_theta) * self.q_hist), np.float32)
+        des[:, :self.q_hist] = self._sample(cubes[0], ys, xs)
+        col = self.q_hist
+        for r in range(self.q_radius):
+            rad = self.radius * (r + 1) / self.q_radius
+            for j in range(self.q_theta):
+                ang = 2.0 * np.pi * j / self.q_theta
+                des[:, col:col + self.q_hist] = self._sample(cubes[r], ys + rad * np.sin(ang), xs + rad * np.cos(ang))
+                col += self.q_hist
+        return des
+
+
+def knn2(query: np.ndarray, train: np.ndarray, block: int = 2048):
+    """Exact two nearest neighbours (L2) of every query row in `train`: (idx (n,2), dist (n,2))."""
+    q = np.ascontiguousarray(query, np.float32)
+    t = np.ascontiguousarray(train, np.float32)
+    tn = np.einsum("ij,ij->i", t, t)
+    idx = np.empty((len(q), 2), np.int64)
+    dist = np.empty((len(q), 2), np.float32)
+    for s in range(0, len(q), block):
+        qb = q[s:s + block]
+        d2 = np.einsum("ij,ij->i", qb, qb)[:, None] + tn[None, :] - 2.0 * (qb @ t.T)
+        part = np.argpartition(d2, 1, axis=1)[:, :2]
+        dd = np.take_along_axis(d2, part, axis=1)
+        order = np.argsort(dd, axis=1)
+        idx[s:s + block] = np.take_along_axis(part, order, axis=1)
+        dist[s:s + block] = np.sqrt(np.maximum(np.take_along_axis(dd, order, axis=1), 0))
+    return idx, dist
+
+
+def _fit_similarity(src: np.ndarray, dst: np.ndarray) -> Optional[np.ndarray]:
+    """Least-squares 4-DOF transform dst ~ [[a, -b, tx], [b, a, ty]] @ (src, 1)."""
+    n = len(src)
+    A = np.zeros((2 * n, 4))
+    A[0::2, 0], A[0::2, 1], A[0::2, 2] = src[:, 0], -src[:, 1], 1.0
+    A[1::2, 0], A[1::2, 1], A[1::2, 3] = src[:, 1], src[:, 0], 1.0
+    sol, _, rank, _ = np.linalg.lstsq(A, dst.reshape(-1), rcond=None)
+    if rank < 4:
+        return None
+    a, b, tx, ty = sol
+    return np.array([[a, -b, tx], [b, a, ty]], np.float64)
+
+
+def estimate_affine_partial_2d(src_pts: np.ndarray, dst_pts: np.ndarray, confidence: float = 0.99,
+                               reproj_threshold: float = 3.0, max_iters: int = 2000, seed: int = 0):
+    """Counterpart of cv.estimateAffinePartial2D(src, dst, method=RANSAC, confidence=0.99): similarity transform
+    (rotation, uniform scale, translation) mapping src to dst, robust to outliers.  Returns (2x3 matrix or None,
+    inlier mask)."""
+    src = np.asarray(src_pts, np.float64).reshape(-1, 2)
+    dst = np.asarray(dst_pts, np.float64).reshape(-1, 2)
+    n = len(src)
+    if n < 2:
+        return None, np.zeros(n, bool)
+    rng = np.random.default_rng(seed)
+    best_mask, best_count, iters, it = None, 0, max_iters, 0
+    thr2 = reproj_threshold * reproj_threshold
+    while it < iters:
+        it += 1
+        i, j = rng.choice(n, 2, replace=False)
+        if np.allclose(src[i], src[j]):
+            continue
+        M = _fit_similarity(src[[i, j]], dst[[i, j]])
+        if M is None:
+            continue
+        err = ((src @ M[:, :2].T + M[:, 2] - dst) ** 2).sum(1)
+        mask = err < thr2
+        count = int(mask.sum())
+        if count > best_count:
+            best_count, best_mask = count, mask
+            w = count / n
+            denom = np.log(max(1.0 - w * w, 1e-12))
+            iters = min(max_iters, int(np.ceil(np.log(1.0 - confidence) / denom))) if denom < 0 else it
+    if best_mask is None or best_count < 2:
+        return None, np.zeros(n, bool)
+    M = _fit_similarity(src[best_mask], dst[best_mask])
+    if M is None:
+        return None, best_mask
+    for _ in range(10):     # re-select the inliers of the refined model (OpenCV refines on the inlier set)
+        err = ((src @ M[:, :2].T + M[:, 2] - dst) ** 2).sum(1)
+        mask = err < thr2
+        if mask.sum() < 2 or np.array_equal(mask, best_mask):
+            break
+        best_mask = mask
+        M2 = _fit_similarity(src[mask], dst[mask])
+        if M2 is None:
+            break
+        M = M2
+    return M, best_mask

@@ -91,3 +91,22 @@ def _cast(img, dtype):
     if dtype == np.uint16:
         return np.clip(np.rint(img * 257.0), 0, 65535).astype(np.uint16)
     raise ValueError(f"unsupported dtype {dtype}")
+
+
+def make_cells(H, W, n=None, seed=1, dtype=np.uint16):
+    """Fluorescence-like test image: `n` blurred point sources of random brightness (two spot sizes) plus a little
+    noise.  Unlike the smooth field of make_pair it has distinctive local constellations, which is what the
+    feature-based registration needs."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    n = n if n is not None else max(H * W // 400, 16)
+    pts = np.zeros((H, W), np.float32)
+    pts[rng.integers(0, H, n), rng.integers(0, W, n)] = rng.uniform(0.3, 1.0, n).astype(np.float32)
+    img = gaussian_filter(pts, 2.0) + 0.5 * gaussian_filter(np.roll(pts, 7, 0), 4.5)
+    img += rng.normal(0, 0.02 * float(img.max()), img.shape).astype(np.float32)
+    img = np.clip(img / float(img.max()), 0, 1)
+    if np.dtype(dtype) == np.uint8:
+        return (img * 255).astype(np.uint8)
+    if np.dtype(dtype) == np.uint16:
+        return (img * 60000).astype(np.uint16)
+    return (img * 255).astype(np.float32)

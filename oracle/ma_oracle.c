@@ -515,13 +515,23 @@ void orc_remap_tables(float* tab_f /*1024*4*/, short* tab_i /*1024*4*/)
     memcpy(tab_i, g_tab_i, sizeof(short) * INTER_TAB_SIZE * INTER_TAB_SIZE * 4);
 }
 
-#define REMAP_BODY(T, WT, KT, LOADW, CASTEXPR)                                                      \
+/* fixed-point source coordinates (5 fractional bits) of destination pixel (x, y): from a float map ... */
+#define COORDS_FROM_MAP                                                                         \
+    const float* mrow = map + (size_t)y * dw * 2;                                               \
+    int sxq = cv_round_f(mrow[x * 2] * INTER_TAB_SIZE);                                         \
+    int syq = cv_round_f(mrow[x * 2 + 1] * INTER_TAB_SIZE);
+/* ... or from the inverted affine matrix as WarpAffineInvoker computes them (imgwarp.cpp, AB_BITS = 10) */
+#define COORDS_FROM_AFFINE                                                                      \
+    int sxq = (X0 + adelta[x]) >> (AB_BITS - INTER_BITS);                                       \
+    int syq = (Y0 + bdelta[x]) >> (AB_BITS - INTER_BITS);
+
+#define REMAP_BODY(T, WT, KT, LOADW, CASTEXPR) REMAP_BODY_X(T, WT, KT, LOADW, CASTEXPR, , COORDS_FROM_MAP)
+#define REMAP_BODY_X(T, WT, KT, LOADW, CASTEXPR, ROWSETUP, COORDS)                                  \
     for (int y = 0; y < dh; y++) {                                                              \
-        const float* mrow = map + (size_t)y * dw * 2;                                           \
         T* drow = (T*)dst + (size_t)y * dw * cn;                                                \
+        ROWSETUP                                                                                \
         for (int x = 0; x < dw; x++) {                                                          \
-            int sxq = cv_round_f(mrow[x * 2] * INTER_TAB_SIZE);                                 \
-            int syq = cv_round_f(mrow[x * 2 + 1] * INTER_TAB_SIZE);                             \
+            COORDS                                                                              \
             int a = (syq & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (sxq & (INTER_TAB_SIZE - 1)); \
             int sx = sat_short(sxq >> INTER_BITS), sy = sat_short(syq >> INTER_BITS);           \
             const KT* wgt = LOADW[a];                                                           \
@@ -560,6 +570,65 @@ int orc_remap_bilinear(const void* src, int dtype, int cn, int sh, int sw,
     } else
         return ORC_EINVAL;
     return ORC_OK;
+}
+
+/* cv2.warpAffine(src, M, dsize) with the default flags (INTER_LINEAR, BORDER_CONSTANT 0), as
+ * feature_registrator.py:130 calls it [OCV-mem, imgwarp.cpp cv::warpAffine + WarpAffineInvoker]:
+ * M (forward, 2x3 double) is inverted in double; per destination column adelta/bdelta =
+ * saturate_cast<int>(M0*x*1024), (M3*x*1024); per row X0 = saturate_cast<int>((M1*y + M2)*1024) + 16 (half of
+ * 1/32 px in 10-bit fixed point); X = (X0 + adelta[x]) >> 5 carries 5 fractional bits and feeds the same
+ * bilinear tables as remap. */
+#define AB_BITS 10
+#define AB_SCALE (1 << AB_BITS)
+static int sat_int_d(double v)
+{
+    if (!(v > -2147483648.0)) return INT32_MIN;
+    if (!(v < 2147483647.0)) return INT32_MAX;
+    return (int)lrint(v);
+}
+
+int orc_warp_affine_cv(const void* src, int dtype, int sh, int sw, const double* M_fwd, int dh, int dw, void* dst)
+{
+    if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || !M_fwd) return ORC_EINVAL;
+    const int cn = 1;
+    init_bilinear_tab();
+    double M[6];
+    memcpy(M, M_fwd, sizeof(M));
+    {
+        double D = M[0] * M[4] - M[1] * M[3];
+        D = D != 0 ? 1. / D : 0;
+        double A11 = M[4] * D, A22 = M[0] * D;
+        M[0] = A11; M[1] *= -D;
+        M[3] *= -D; M[4] = A22;
+        double b1 = -M[0] * M[2] - M[1] * M[5];
+        double b2 = -M[3] * M[2] - M[4] * M[5];
+        M[2] = b1; M[5] = b2;
+    }
+    int* adelta = (int*)malloc(sizeof(int) * 2 * (size_t)dw);
+    if (!adelta) return ORC_EINVAL;
+    int* bdelta = adelta + dw;
+    for (int x = 0; x < dw; x++) {
+        adelta[x] = sat_int_d(M[0] * x * AB_SCALE);
+        bdelta[x] = sat_int_d(M[3] * x * AB_SCALE);
+    }
+    const int round_delta = AB_SCALE / INTER_TAB_SIZE / 2;
+#define AFFINE_ROW                                                                              \
+    const int X0 = sat_int_d((M[1] * y + M[2]) * AB_SCALE) + round_delta;                       \
+    const int Y0 = sat_int_d((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+    int rc = ORC_OK;
+    if (dtype == ORC_U8) {
+        REMAP_BODY_X(uint8_t, int, short, g_tab_i,
+                     (uint8_t)clampi((acc + (1 << (INTER_REMAP_COEF_BITS - 1))) >> INTER_REMAP_COEF_BITS, 0, 255),
+                     AFFINE_ROW, COORDS_FROM_AFFINE)
+    } else if (dtype == ORC_U16) {
+        REMAP_BODY_X(uint16_t, float, float, g_tab_f, (uint16_t)clampi(cv_round_f(acc), 0, 65535), AFFINE_ROW,
+                     COORDS_FROM_AFFINE)
+    } else if (dtype == ORC_F32) {
+        REMAP_BODY_X(float, float, float, g_tab_f, acc, AFFINE_ROW, COORDS_FROM_AFFINE)
+    } else
+        rc = ORC_EINVAL;
+    free(adelta);
+    return rc;
 }
 
 /* ------------------------------------------------------------------------- */

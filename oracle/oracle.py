@@ -74,6 +74,9 @@ def lib():
                                                         C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib.orc_remap_tables.restype = None
         _lib.orc_remap_tables.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.orc_warp_affine_cv.restype = C.c_int
+        _lib.orc_warp_affine_cv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_void_p]
     return _lib
 
 
@@ -139,6 +142,21 @@ def remap(src, map_xy):
     dh, dw = map_xy.shape[:2]
     dst = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), src.dtype)
     _check(lib().orc_remap_bilinear(_p(src), dt, cn, sh, sw, _p(map_xy), dh, dw, _p(dst)), "remap")
+    return dst
+
+
+# --- cv2.warpAffine(src, M, dsize=(W, H)) with default flags (INTER_LINEAR, BORDER_CONSTANT 0) ---
+def warp_affine(src, M, dsize=None):
+    src, dt = _img(src)
+    if src.ndim != 2:
+        raise ValueError("warp_affine: 2-D images only")
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    if M.shape != (2, 3):
+        raise ValueError("M must be a 2x3 matrix")
+    sh, sw = src.shape
+    dw, dh = (sw, sh) if dsize is None else dsize
+    dst = np.empty((dh, dw), src.dtype)
+    _check(lib().orc_warp_affine_cv(_p(src), dt, sh, sw, _p(M), dh, dw, _p(dst)), "warp_affine")
     return dst
 
 

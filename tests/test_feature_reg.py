@@ -1,0 +1,166 @@
+"""FeatureRegistrator: the sparse CPU stage on its own (no GPU needed), the cv2.warpAffine
+kernel against the oracle, and the whole class on a known similarity transform (GPU)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from microaligner_amd import synthetic
+from microaligner_amd.feature_reg import sparse_cpu as SP
+from microaligner_amd.feature_reg import tile_registration as TR
+from microaligner_amd.feature_reg.feature_detection import Features, find_features, match_features
+
+
+def _brute_fast(img, t=1):
+    h, w = img.shape
+    out = np.zeros((h, w), np.int32)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            v = int(img[y, x])
+            d = [v - int(img[y + dy, x + dx]) for dx, dy in SP._RING]
+            best = max(max(min(d[(s + j) % 16] for j in range(9)), min(-d[(s + j) % 16] for j in range(9)))
+                       for s in range(16))
+            out[y, x] = best - 1 if best > t else 0
+    return out
+
+
+def test_fast_score_is_the_segment_test_definition():
+    rng = np.random.default_rng(0)
+    for img in ((rng.random((40, 47)) * 255).astype(np.uint8),
+                np.clip(rng.normal(128, 2, (50, 50)), 0, 255).astype(np.uint8)):
+        assert np.array_equal(SP.fast_score_map(img, 1), _brute_fast(img, 1))
+    flat = np.full((30, 30), 77, np.uint8)
+    assert SP.fast_detect(flat) == [] and not SP.fast_score_map(np.zeros((5, 5), np.uint8)).any()
+    spot = flat.copy()
+    spot[15, 15] = 200                              # an isolated bright pixel: one corner, all ring pixels darker
+    kps = SP.fast_detect(spot)
+    assert [k.pt for k in kps] == [(15.0, 15.0)] and kps[0].response == 200 - 77 - 1 and kps[0].size == 7.0
+
+
+def test_nonmax_suppression_keeps_strict_local_maxima():
+    img = synthetic.make_cells(120, 130, seed=2, dtype=np.uint8)
+    s = SP.fast_score_map(img, 1)
+    pts = {(int(k.pt[1]), int(k.pt[0])) for k in SP.fast_detect(img)}
+    assert pts and len(pts) < (s > 0).sum()
+    for y, x in pts:
+        nb = s[y - 1:y + 2, x - 1:x + 2].copy()
+        nb[1, 1] = -1
+        assert s[y, x] > nb.max()
+
+
+def test_knn_and_similarity_fit():
+    rng = np.random.default_rng(1)
+    q, t = rng.random((150, 200)).astype(np.float32), rng.random((260, 200)).astype(np.float32)
+    idx, dist = SP.knn2(q, t, block=64)
+    D = np.sqrt(((q[:, None, :] - t[None]) ** 2).sum(-1))
+    o = np.argsort(D, 1)[:, :2]
+    assert np.array_equal(idx, o) and np.allclose(dist, np.take_along_axis(D, o, 1), atol=1e-3)
+    src = rng.random((300, 2)) * 800
+    th = np.deg2rad(4.0)
+    M = np.array([[1.03 * np.cos(th), -1.03 * np.sin(th), 20.5], [1.03 * np.sin(th), 1.03 * np.cos(th), -11.25]])
+    dst = src @ M[:, :2].T + M[:, 2] + rng.normal(0, 0.2, (300, 2))
+    dst[:100] = rng.random((100, 2)) * 800           # a third of the matches are wrong
+    est, mask = SP.estimate_affine_partial_2d(src, dst)
+    assert np.abs(est - M).max() < 0.05 and 180 <= mask.sum() <= 215 and not mask[:100].sum() > 10
+    assert SP.estimate_affine_partial_2d(src[:1], dst[:1])[0] is None
+
+
+def test_tiles_and_feature_bookkeeping():
+    img = synthetic.make_cells(450, 620, seed=3, dtype=np.uint8)
+    tiles, info = TR.split_image_into_tiles(img, 300)
+    assert len(tiles) == 6 and info["ntiles"] == dict(x=3, y=2) and tiles[0].shape == (402, 402)
+    assert np.array_equal(tiles[4][51:201, 51:351], img[300:450, 300:600]) and not tiles[0][:51].any()
+    f = TR.find_features(img, 300)
+    assert f.is_valid() and f.descriptors.shape == (len(f.keypoints), 200) and f.descriptors.dtype == np.float32
+    xs = np.array([k.pt for k in f.keypoints])
+    assert xs[:, 0].max() < 620 + 3 and xs[:, 1].max() < 450 + 3 and xs.min() >= 0
+    assert not find_features(np.zeros((200, 200), np.uint8)).is_valid()
+    assert np.array_equal(match_features(Features(), f, verbose=False), np.eye(2, 3))
+
+
+def test_sparse_stage_recovers_a_translation():
+    ref = synthetic.make_cells(600, 700, seed=4)
+    M = np.array([[1.0, 0.0, 9.0], [0.0, 1.0, -6.0]])
+    mov = O.warp_affine(ref, M)
+    fr, fm = TR.find_features(O.dog(ref, True), 400), TR.find_features(O.dog(mov, True), 400)
+    T = TR.register_img_pair(fr, fm, verbose=False)          # maps moving -> reference coordinates
+    assert np.abs(T - np.array([[1, 0, -9.0], [0, 1, 6.0]])).max() < 0.15
+
+
+def test_oracle_warp_affine_known_answers():
+    rng = np.random.default_rng(5)
+    img = (rng.random((40, 50)) * 255).astype(np.uint8)
+    assert np.array_equal(O.warp_affine(img, np.eye(2, 3)), img)
+    out = O.warp_affine(img, np.array([[1, 0, 3.0], [0, 1, -2.0]]))
+    exp = np.zeros_like(img)
+    exp[:-2, 3:] = img[2:, :-3]
+    assert np.array_equal(out, exp)
+    f = img.astype(np.float32)
+    half = O.warp_affine(f, np.array([[1, 0, 0.5], [0, 1, 0.0]]))
+    assert np.array_equal(half[:, 1:], 0.5 * (f[:, :-1] + f[:, 1:]))
+    big = O.warp_affine(img, np.array([[2.0, 0, 0], [0, 2.0, 0]]), dsize=(100, 80))
+    assert big.shape == (80, 100) and np.array_equal(big[::2, ::2][:40, :50], img)
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("case", ["rot", "scale", "shift", "far"])
+def test_warp_affine_cv_bit_exact(ctx, dtype, case):
+    rng = np.random.default_rng(7)
+    img = (rng.random((203, 317)) * (60000 if dtype == np.uint16 else 255)).astype(dtype)
+    th = np.deg2rad(7.3)
+    M = {"rot": np.array([[np.cos(th), -np.sin(th), 10.4], [np.sin(th), np.cos(th), -21.7]]),
+         "scale": np.array([[1.37, 0.02, -30.0], [-0.01, 0.81, 12.125]]),
+         "shift": np.array([[1.0, 0.0, 0.484375], [0.0, 1.0, -3.0]]),
+         "far": np.array([[1.0, 0.0, 5000.0], [0.0, 1.0, 0.0]])}[case]
+    got = ctx.warp_affine_cv(ctx.asdevice(img), M).numpy()
+    assert np.array_equal(got, O.warp_affine(img, M))
+    got = ctx.warp_affine_cv(ctx.asdevice(img), M, dsize=(400, 150)).numpy()
+    assert got.shape == (150, 400) and np.array_equal(got, O.warp_affine(img, M, dsize=(400, 150)))
+
+
+@pytest.mark.gpu
+def test_feature_registrator_recovers_a_similarity_transform():
+    from microaligner_amd import FeatureRegistrator, transform_img_with_tmat
+    H, W = 1500, 1700
+    ref = synthetic.make_cells(H, W, seed=6)
+    th = np.deg2rad(0.7)
+    M = np.array([[np.cos(th), -np.sin(th), 17.0], [np.sin(th), np.cos(th), -11.0]])
+    mov = O.warp_affine(ref, M)
+    freg = FeatureRegistrator()
+    freg.verbose = False
+    freg.num_pyr_lvl, freg.tile_size = 2, 500
+    assert freg._factors == [8, 4, 2] and freg.num_iterations == 3 and freg.use_dog is True
+    freg.ref_img, freg.mov_img = ref, mov
+    T = freg.register()
+    assert T.shape == (2, 3) and T.dtype == np.float64
+    Mi = np.linalg.inv(np.vstack([M, [0, 0, 1]]))[:2]
+    assert np.abs(T[:, :2] - Mi[:, :2]).max() < 2e-3 and np.abs(T[:, 2] - Mi[:, 2]).max() < 2.0
+    aligned = transform_img_with_tmat(mov, (H, W), T)
+    inner = (slice(100, -100), slice(100, -100))
+    before = np.abs(mov[inner].astype(np.float64) - ref[inner]).mean()
+    after = np.abs(aligned[inner].astype(np.float64) - ref[inner]).mean()
+    assert after < 0.35 * before
+    # reuse_ref_img keeps the reference features (the pipeline registers many cycles against one reference)
+    feats = freg._ref_pyr_features
+    freg.mov_img = mov
+    T2 = freg.register(reuse_ref_img=True)
+    assert freg._ref_pyr_features is feats and np.allclose(T2, T)
+
+
+@pytest.mark.gpu
+def test_feature_registrator_helpers():
+    from microaligner_amd import FeatureRegistrator
+    f = FeatureRegistrator()
+    a, b = np.array([[1.0, 0, 5], [0, 1, -2]]), np.array([[0.0, -1, 0], [1, 0, 3]])
+    assert np.allclose(f._multiply_transform_matrices([a, b]), (np.vstack([a, [0, 0, 1]]) @ np.vstack([b, [0, 0, 1]]))[:2])
+    assert np.array_equal(f._rescale_t_mat(a, 4), np.array([[1.0, 0, 20], [0, 1, -8]]))
+    assert f._check_if_proper_scale(a) and not f._check_if_proper_scale(a * np.array([[5, 5, 1]] * 2))
+    assert not f._check_if_proper_scale(np.zeros((2, 3)))
+    assert f._check_if_inside_borders(a, (100, 100)) and not f._check_if_inside_borders(np.array([[1.0, 0, 500], [0, 1, 0]]), (100, 100))
+    with pytest.raises(ValueError):
+        f.ref_img = np.zeros((3, 3, 3))
+    f.num_pyr_lvl = 0
+    f.ref_img = f.mov_img = np.zeros((300, 300), np.uint8)
+    with pytest.raises(ValueError, match="use_full_res_img"):
+        f.register()
