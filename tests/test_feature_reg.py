@@ -164,3 +164,37 @@ def test_feature_registrator_helpers():
     f.ref_img = f.mov_img = np.zeros((300, 300), np.uint8)
     with pytest.raises(ValueError, match="use_full_res_img"):
         f.register()
+
+
+@pytest.mark.gpu
+def test_affine_init_then_optical_flow_refine():
+    """BASELINE cfg5 in miniature: feature-based affine initialisation, then the optical-flow refinement on the
+    affinely aligned image (the reference pipeline's two stages, __main__.py:257-286 then :398-433)."""
+    from microaligner_amd import FeatureRegistrator, OptFlowRegistrator, Warper, transform_img_with_tmat
+    H, W = 1200, 1300
+    ref = synthetic.make_cells(H, W, seed=8)
+    th = np.deg2rad(0.5)
+    M = np.array([[np.cos(th), -np.sin(th), 11.0], [np.sin(th), np.cos(th), -8.0]])
+    mov = O.warp_affine(ref, M)
+    # a smooth non-linear residual on top of the affine part
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    m = np.stack([xs + 1.5 * np.sin(ys / 90.0), ys + 1.5 * np.cos(xs / 110.0)], -1)
+    mov = O.remap(mov, m)
+    freg = FeatureRegistrator()
+    freg.verbose = False
+    freg.num_pyr_lvl, freg.tile_size = 2, 500
+    freg.ref_img, freg.mov_img = ref, mov
+    T = freg.register()
+    affine = transform_img_with_tmat(mov, (H, W), T)
+    ofreg = OptFlowRegistrator()
+    ofreg.verbose = False
+    ofreg.num_pyr_lvl, ofreg.tile_size, ofreg.overlap, ofreg.use_full_res_img, ofreg.use_dog = 2, 400, 60, True, True
+    ofreg.ref_img, ofreg.mov_img = ref, affine
+    flow = ofreg.register()
+    w = Warper()
+    w.tile_size, w.overlap = 400, 60
+    w.image, w.flow = affine, flow
+    final = w.warp()
+    inner = (slice(120, -120), slice(120, -120))
+    err = [np.abs(a[inner].astype(np.float64) - ref[inner]).mean() for a in (mov, affine, final)]
+    assert err[1] < 0.5 * err[0] and err[2] < 0.8 * err[1]
