@@ -42,6 +42,8 @@ __device__ __forceinline__ T pyr_down_px(const T* __restrict__ src, int h, int w
 // A thread produces the destination pair (2p, 2p+1) of row y from source columns 4p-2 .. 4p+4: one 2-vector, one
 // 4-vector and one scalar load per source row instead of ten scalar loads (vec: w % 4 == 0, so the vectors are
 // aligned).  Pairs that touch the left/right border and everything when !vec take the per-pixel path.
+// PD_ROWS destination rows per thread: their 2*PD_ROWS + 3 source rows are loaded once (all loads issued up front)
+constexpr int PD_ROWS = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void pyr_down_kernel(const T* __restrict__ src, int h, int w, T* __restrict__ dst,
                                                        int dh, int dw, int vec)
@@ -49,29 +51,46 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const T* __restrict__ src
     using A = typename PyrAcc<T>::type;
     using V2 = typename PyrVec<T>::v2;
     using V4 = typename PyrVec<T>::v4;
-    const int p = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    constexpr int NR = 2 * PD_ROWS + 3;
+    const int p = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * PD_ROWS;
     const int x0 = 2 * p;
     if (x0 >= dw) return;
-    T* drow = dst + (size_t)y * dw;
     if (!vec || p == 0 || 4 * p + 4 >= w || x0 + 1 >= dw) {
-        drow[x0] = pyr_down_px<T>(src, h, w, x0, y);
-        if (x0 + 1 < dw) drow[x0 + 1] = pyr_down_px<T>(src, h, w, x0 + 1, y);
+        for (int r = 0; r < PD_ROWS && y0 + r < dh; r++) {
+            T* drow = dst + (size_t)(y0 + r) * dw;
+            drow[x0] = pyr_down_px<T>(src, h, w, x0, y0 + r);
+            if (x0 + 1 < dw) drow[x0 + 1] = pyr_down_px<T>(src, h, w, x0 + 1, y0 + r);
+        }
         return;
     }
-    A ra[5], rb[5];
+    V2 l[NR];
+    V4 m[NR];
+    T e[NR];
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const T* s = src + (size_t)d_reflect101(2 * y + k - 2, h) * w + 4 * p;
-        const V2 l = *reinterpret_cast<const V2*>(s - 2);
-        const V4 m = *reinterpret_cast<const V4*>(s);
-        const A c0 = (A)l.x, c1 = (A)l.y, c2 = (A)m.x, c3 = (A)m.y, c4 = (A)m.z, c5 = (A)m.w, c6 = (A)s[4];
+    for (int k = 0; k < NR; k++) {
+        // rows past the last destination row of a partial group are clamped (loaded, not used)
+        const T* s = src + (size_t)d_reflect101(min(2 * y0 + k - 2, 2 * (dh - 1) + 2), h) * w + 4 * p;
+        l[k] = *reinterpret_cast<const V2*>(s - 2);
+        m[k] = *reinterpret_cast<const V4*>(s);
+        e[k] = s[4];
+    }
+    A ra[NR], rb[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        const A c0 = (A)l[k].x, c1 = (A)l[k].y, c2 = (A)m[k].x, c3 = (A)m[k].y, c4 = (A)m[k].z, c5 = (A)m[k].w, c6 = (A)e[k];
         ra[k] = c2 * 6 + (c1 + c3) * 4 + c0 + c4;
         rb[k] = c4 * 6 + (c3 + c5) * 4 + c2 + c6;
     }
-    const T oa = pyr_down_finish<T>(ra[2] * 6 + (ra[1] + ra[3]) * 4 + ra[0] + ra[4]);
-    const T ob = pyr_down_finish<T>(rb[2] * 6 + (rb[1] + rb[3]) * 4 + rb[0] + rb[4]);
-    if ((dw & 1) == 0) { V2 o; o.x = oa; o.y = ob; *reinterpret_cast<V2*>(drow + x0) = o; }
-    else { drow[x0] = oa; drow[x0 + 1] = ob; }
+#pragma unroll
+    for (int r = 0; r < PD_ROWS; r++) {
+        if (y0 + r >= dh) break;
+        const int k = 2 * r;
+        const T oa = pyr_down_finish<T>(ra[k + 2] * 6 + (ra[k + 1] + ra[k + 3]) * 4 + ra[k] + ra[k + 4]);
+        const T ob = pyr_down_finish<T>(rb[k + 2] * 6 + (rb[k + 1] + rb[k + 3]) * 4 + rb[k] + rb[k + 4]);
+        T* drow = dst + (size_t)(y0 + r) * dw;
+        if ((dw & 1) == 0) { V2 o; o.x = oa; o.y = ob; *reinterpret_cast<V2*>(drow + x0) = o; }
+        else { drow[x0] = oa; drow[x0 + 1] = ob; }
+    }
 }
 
 // horizontally upsampled value of one source row at destination column X (two channels)
@@ -106,47 +125,61 @@ __device__ __forceinline__ float2 pyr_up_px(const float2* __restrict__ src, int 
     return make_float2(((r1.x + r2.x) * 4) * (1.f / 64), ((r1.y + r2.y) * 4) * (1.f / 64));
 }
 
-// A thread produces the 2x2 destination cell (2x..2x+1, 2y..2y+1) from the 3x3 source neighbourhood of (x, y):
-// 9 loads for 4 outputs instead of 25, and 16-byte stores.  Cells on the source border (and the extra
-// row/column of odd destination sizes) take the per-pixel path; same operations in the same order either way.
+// A thread produces PU_ROWS vertically adjacent 2x2 destination cells (2x..2x+1, 2y..2y+1) from the
+// (PU_ROWS + 2) x 3 source neighbourhood: 3 loads per source row, all issued up front, 16-byte stores.  Cells on the
+// source border (and the extra row/column of odd destination sizes) take the per-pixel path; same operations in
+// the same order either way.
+constexpr int PU_ROWS = 4;
 __global__ __launch_bounds__(256) void pyr_up_flow_kernel(const float2* __restrict__ src, int h, int w, float scale,
                                                           float2* __restrict__ dst, int dh, int dw)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    const int X = 2 * x, Y = 2 * y;
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * PU_ROWS;
+    const int X = 2 * x;
     if (X >= dw) return;
-    if (x < 1 || x > w - 2 || y < 1 || y > h - 2) {
-        for (int j = 0; j < 2; j++)
-            for (int i = 0; i < 2; i++)
-                if (X + i < dw && Y + j < dh)
-                    dst[(size_t)(Y + j) * dw + X + i] = pyr_up_px(src, h, w, scale, X + i, Y + j, dw);
+    if (x < 1 || x > w - 2 || y0 < 1 || y0 + PU_ROWS - 1 > h - 2) {
+        for (int r = 0; r < PU_ROWS; r++)
+            for (int j = 0; j < 2; j++)
+                for (int i = 0; i < 2; i++) {
+                    const int Y = 2 * (y0 + r) + j;
+                    if (X + i < dw && Y < dh) dst[(size_t)Y * dw + X + i] = pyr_up_px(src, h, w, scale, X + i, Y, dw);
+                }
         return;
     }
-    float2 ev[3], od[3];  // horizontally upsampled rows y-1, y, y+1 at X (even) and X+1 (odd)
+    float2 ev[PU_ROWS + 2], od[PU_ROWS + 2];  // horizontally upsampled source rows y0-1 .. y0+PU_ROWS at X and X+1
+    {
+        float2 a[PU_ROWS + 2], b[PU_ROWS + 2], c[PU_ROWS + 2];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const float2* s = src + (size_t)(y + k - 1) * w + x;
-        float2 a = s[-1], b = s[0], c = s[1];
-        a.x *= scale; a.y *= scale; b.x *= scale; b.y *= scale; c.x *= scale; c.y *= scale;
-        ev[k] = make_float2(a.x + b.x * 6 + c.x, a.y + b.y * 6 + c.y);
-        od[k] = make_float2((b.x + c.x) * 4, (b.y + c.y) * 4);
+        for (int k = 0; k < PU_ROWS + 2; k++) {
+            const float2* s = src + (size_t)(y0 + k - 1) * w + x;
+            a[k] = s[-1]; b[k] = s[0]; c[k] = s[1];
+        }
+#pragma unroll
+        for (int k = 0; k < PU_ROWS + 2; k++) {
+            const float ax = a[k].x * scale, ay = a[k].y * scale, bx = b[k].x * scale, by = b[k].y * scale,
+                        cx = c[k].x * scale, cy = c[k].y * scale;
+            ev[k] = make_float2(ax + bx * 6 + cx, ay + by * 6 + cy);
+            od[k] = make_float2((bx + cx) * 4, (by + cy) * 4);
+        }
     }
-    float4 top, bot;
-    top.x = (ev[0].x + ev[1].x * 6 + ev[2].x) * (1.f / 64);
-    top.y = (ev[0].y + ev[1].y * 6 + ev[2].y) * (1.f / 64);
-    top.z = (od[0].x + od[1].x * 6 + od[2].x) * (1.f / 64);
-    top.w = (od[0].y + od[1].y * 6 + od[2].y) * (1.f / 64);
-    bot.x = ((ev[1].x + ev[2].x) * 4) * (1.f / 64);
-    bot.y = ((ev[1].y + ev[2].y) * 4) * (1.f / 64);
-    bot.z = ((od[1].x + od[2].x) * 4) * (1.f / 64);
-    bot.w = ((od[1].y + od[2].y) * 4) * (1.f / 64);
-    float2* d0 = dst + (size_t)Y * dw + X;
-    if ((dw & 1) == 0) {
-        *reinterpret_cast<float4*>(d0) = top;
-        *reinterpret_cast<float4*>(d0 + dw) = bot;
-    } else {
-        d0[0] = make_float2(top.x, top.y); d0[1] = make_float2(top.z, top.w);
-        d0[dw] = make_float2(bot.x, bot.y); d0[dw + 1] = make_float2(bot.z, bot.w);
+#pragma unroll
+    for (int r = 0; r < PU_ROWS; r++) {
+        float4 top, bot;   // rows of cell r: source rows r (above), r+1 (centre), r+2 (below)
+        top.x = (ev[r].x + ev[r + 1].x * 6 + ev[r + 2].x) * (1.f / 64);
+        top.y = (ev[r].y + ev[r + 1].y * 6 + ev[r + 2].y) * (1.f / 64);
+        top.z = (od[r].x + od[r + 1].x * 6 + od[r + 2].x) * (1.f / 64);
+        top.w = (od[r].y + od[r + 1].y * 6 + od[r + 2].y) * (1.f / 64);
+        bot.x = ((ev[r + 1].x + ev[r + 2].x) * 4) * (1.f / 64);
+        bot.y = ((ev[r + 1].y + ev[r + 2].y) * 4) * (1.f / 64);
+        bot.z = ((od[r + 1].x + od[r + 2].x) * 4) * (1.f / 64);
+        bot.w = ((od[r + 1].y + od[r + 2].y) * 4) * (1.f / 64);
+        float2* d0 = dst + (size_t)(2 * (y0 + r)) * dw + X;
+        if ((dw & 1) == 0) {
+            *reinterpret_cast<float4*>(d0) = top;
+            *reinterpret_cast<float4*>(d0 + dw) = bot;
+        } else {
+            d0[0] = make_float2(top.x, top.y); d0[1] = make_float2(top.z, top.w);
+            d0[dw] = make_float2(bot.x, bot.y); d0[dw + 1] = make_float2(bot.z, bot.w);
+        }
     }
 }
 
@@ -163,7 +196,7 @@ int ma_pyr_down(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst
     MA_REQUIRE(dh <= 65535, "image too tall");
     MA_HIP(hipSetDevice(ctx->device));
     MaProfScope ps(ctx, MA_K_PYR_DOWN, (double)h * w);
-    dim3 grid(((dw + 1) / 2 + 255) / 256, dh), block(256);
+    dim3 grid(((dw + 1) / 2 + 255) / 256, (dh + PD_ROWS - 1) / PD_ROWS), block(256);
     const int vec = (w % 4 == 0) && ((size_t)src % 16 == 0) && ((size_t)dst % 8 == 0);
     if (dtype == MA_U8) hipLaunchKernelGGL((pyr_down_kernel<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)src, h, w, (uint8_t*)dst, dh, dw, vec);
     else if (dtype == MA_U16) hipLaunchKernelGGL((pyr_down_kernel<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)src, h, w, (uint16_t*)dst, dh, dw, vec);
@@ -181,7 +214,7 @@ int ma_pyr_up_flow(ma_ctx* ctx, const float* src, int h, int w, float scale, flo
     MA_HIP(hipSetDevice(ctx->device));
     MaProfScope ps(ctx, MA_K_PYR_UP, (double)dh * dw);
     MA_REQUIRE((size_t)dst % 16 == 0, "dst must be 16-byte aligned");
-    hipLaunchKernelGGL(pyr_up_flow_kernel, dim3(((dw + 1) / 2 + 255) / 256, (dh + 1) / 2), dim3(256), 0, ctx->stream,
+    hipLaunchKernelGGL(pyr_up_flow_kernel, dim3(((dw + 1) / 2 + 255) / 256, ((dh + 1) / 2 + PU_ROWS - 1) / PU_ROWS), dim3(256), 0, ctx->stream,
                        (const float2*)src, h, w, scale, (float2*)dst, dh, dw);
     MA_HIP(hipGetLastError());
     return MA_OK;
