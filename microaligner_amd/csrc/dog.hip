@@ -66,11 +66,30 @@ __global__ __launch_bounds__(256) void minmax_partial(const T* __restrict__ src,
     block_minmax_256(lo, hi, part + blockIdx.x * 2);
 }
 
-__global__ __launch_bounds__(256) void minmax_final(const float* __restrict__ part, int nparts, float* __restrict__ out)
+// one block of 1024 threads folds all partial (min, max) pairs; 4 independent 8-byte loads per lane and step
+constexpr int MMF_T = 1024;
+__global__ __launch_bounds__(MMF_T) void minmax_final(const float* __restrict__ part, int nparts, float* __restrict__ out)
 {
     float lo = INFINITY, hi = -INFINITY;
-    for (int i = threadIdx.x; i < nparts; i += 256) { lo = fminf(lo, part[i * 2]); hi = fmaxf(hi, part[i * 2 + 1]); }
-    block_minmax_256(lo, hi, out);
+    const float2* p2 = reinterpret_cast<const float2*>(part);
+    for (int i0 = threadIdx.x; i0 < nparts; i0 += 4 * MMF_T) {
+        float2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = p2[min(i0 + u * MMF_T, nparts - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { lo = fminf(lo, v[u].x); hi = fmaxf(hi, v[u].y); }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_down(lo, off));
+        hi = fmaxf(hi, __shfl_down(hi, off));
+    }
+    __shared__ float slo[MMF_T / 64], shi[MMF_T / 64];
+    if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < MMF_T / 64; k++) { lo = fminf(lo, slo[k]); hi = fmaxf(hi, shi[k]); }
+        out[0] = lo; out[1] = hi;
+    }
 }
 
 constexpr int MM_BLOCKS = 2048;
@@ -112,7 +131,7 @@ int launch_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, float* part
     if (dtype == MA_U8) hipLaunchKernelGGL((minmax_partial<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)src, n, part);
     else if (dtype == MA_U16) hipLaunchKernelGGL((minmax_partial<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint16_t*)src, n, part);
     else hipLaunchKernelGGL((minmax_partial<float>), dim3(blocks), dim3(256), 0, ctx->stream, (const float*)src, n, part);
-    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, ctx->stream, part, blocks, out2);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, blocks, out2);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }
@@ -420,12 +439,12 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     const dim3 cgrid((w + 63) / 64, (h + DC_NW * DC_R - 1) / (DC_NW * DC_R));
     const size_t nblk = (size_t)cgrid.x * cgrid.y;
     const size_t npart = nblk > MM_BLOCKS ? nblk : MM_BLOCKS;
-    const size_t bytes = n * 3 * sizeof(float) + npart * 2 * sizeof(float) + 256;
+    const size_t bytes = n * 3 * sizeof(float) + npart * 2 * sizeof(float) + 256 + 16;
     MA_TRY(ma_ws_reserve(ctx, bytes));
     float* tlo = (float*)ctx->ws;
     float* thi = tlo + n;
     float* diff = thi + n;
-    float* part = diff + n;
+    float* part = (float*)ma_align_up((size_t)(diff + n), 16);  // read as float2 pairs by minmax_final
     DogScalars* sc = (DogScalars*)(part + npart * 2);
     MA_REQUIRE((h + DR - 1) / DR <= 65535, "image too tall");
 
@@ -452,7 +471,7 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     else
         hipLaunchKernelGGL((dog_cols_diff<16, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
                            ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
-    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(256), 0, ctx->stream, part, (int)nblk, sc->mm_diff);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, (int)nblk, sc->mm_diff);
     hipLaunchKernelGGL(dog_params_out, dim3(1), dim3(1), 0, ctx->stream, sc);
     hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst);
     MA_HIP(hipGetLastError());
