@@ -24,8 +24,13 @@ GROUP = {"fb_polyexp_m0": "polyexp_m0", "fb_blur_v": "blur_v", "fb_blur_h_solve"
          "scale_to_u8": "dog", "minmax_partial": "dog", "minmax_final": "dog", "dog_params_in": "dog",
          "dog_params_out": "dog", "joint_hist_kernel": "nmi", "nmi_reduce_kernel": "nmi"}
 
+def newest(pattern):
+    """gpurun merges new files next to those of earlier calls: take the most recent match."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 # 1. kernel stats (rocprofv3 --kernel-trace --stats)
-stats = glob.glob(os.path.join(out, "kt", "*", "*_kernel_stats.csv"))[0]
+stats = newest(os.path.join(out, "kt", "*", "*_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(prof, f"{tag}_kernel_stats_cfg3.csv"), "w") as f:
     w = csv.writer(f)
@@ -37,7 +42,7 @@ with open(os.path.join(prof, f"{tag}_kernel_stats_cfg3.csv"), "w") as f:
 # 2. HBM traffic per kernel (separate --pmc passes; FETCH_SIZE is doubled per MI355X_MICROARCH.md, HBM section)
 tot = {}
 for name in ("fetch", "write"):
-    f = glob.glob(os.path.join(out, name, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(out, name, "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
