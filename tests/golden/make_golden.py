@@ -91,6 +91,8 @@ def _install_standins():
     skm = types.ModuleType("sklearn.metrics")
 
     def normalized_mutual_info_score(a, b):
+        # dog() hands back an all-zero image unchanged (img.max() == 0): one label whatever the dtype
+        a, b = (x if x.dtype == np.uint8 or x.any() else np.zeros(x.shape, np.uint8) for x in (a, b))
         assert a.dtype == np.uint8 and b.dtype == np.uint8
         return O.nmi_u8(a, b)
 

@@ -198,3 +198,42 @@ def test_affine_init_then_optical_flow_refine():
     inner = (slice(120, -120), slice(120, -120))
     err = [np.abs(a[inner].astype(np.float64) - ref[inner]).mean() for a in (mov, affine, final)]
     assert err[1] < 0.5 * err[0] and err[2] < 0.8 * err[1]
+
+
+FEATURE_INDEX = __import__("json").load(open(__import__("os").path.join(
+    __import__("os").path.dirname(__file__), "golden", "feature_index.json")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(FEATURE_INDEX))
+def test_feature_registrator_reproduces_the_reference_orchestration(name):
+    """Fixtures made by the REFERENCE's FeatureRegistrator class driven over the oracle / sparse_cpu primitives
+    (tests/golden/make_feature_golden.py): same levels, same match counts, same gate decisions, same matrix."""
+    import contextlib
+    import io
+    import re
+    from microaligner_amd import FeatureRegistrator
+    case = FEATURE_INDEX[name]
+    H, W = case["shape"]
+    dt = np.dtype(case["dtype"])
+    ref = synthetic.make_cells(H, W, seed=case["seed"], dtype=dt)
+    if case["M"] is None:
+        mov = synthetic.make_cells(H, W, seed=case["seed"] + 1000, dtype=dt)
+    else:
+        th, sc, tx, ty = case["M"]
+        th = np.deg2rad(th)
+        mov = O.warp_affine(ref, np.array([[sc * np.cos(th), -sc * np.sin(th), tx], [sc * np.sin(th), sc * np.cos(th), ty]]))
+    freg = FeatureRegistrator()
+    for k, v in case["params"].items():
+        setattr(freg, k, v)
+    freg.ref_img, freg.mov_img = ref, mov
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        T = freg.register()
+    log = buf.getvalue()
+    assert [int(f) for f in re.findall(r"Pyramid factor (\d+)", log)] == case["factors"]
+    assert [[int(a), int(b)] for a, b in re.findall(r"Good matches (\d+) / (\d+)", log)] == case["good_matches"]
+    assert [("Better" in ln) for ln in log.splitlines() if "alignment than before" in ln] == case["accepted"]
+    mi = [(float(a), float(b)) for a, b in re.findall(r"MI score after: (\S+) \| MI score before: (\S+)", log)]
+    assert np.allclose(mi, case["mi"], rtol=0, atol=1e-12)
+    assert np.allclose(T, np.array(case["t_mat"]), rtol=0, atol=1e-9)
