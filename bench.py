@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 
 METRIC = "Mpix/s optical-flow reg+warp, 16k×16k float32 tile, 1/2/4/8 GPU"  # BASELINE.json
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PK_PEAK_TLOPS = 71.4  # packed FP32 lane-ops/s measured with v_pk_mul_f32 at 8 waves/SIMD (profiles/r01_ubench_valu.txt)
 
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
@@ -67,7 +68,7 @@ def pmc_traffic(workload):
     return json.load(open(files[-1])).get("per_bench_group_bytes_per_step", {})
 
 
-def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None):
+def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsize_taps=0):
     if rec["launches"] == 0 or rec["ms"] <= 0:
         return None
     bpp = algorithmic_bytes_per_px(name, iters, esz)
@@ -75,11 +76,20 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None):
     traffic = None
     if traffic_per_step and name in traffic_per_step:
         traffic = round(traffic_per_step[name] * steps / rec["launches"])  # HBM bytes per launch (PMC)
-    return {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "avg_launch_ms": round(rec["ms"] / rec["launches"], 4), "launches": rec["launches"],
-            "algorithmic_bytes_per_launch": round(bpp * rec["px"] / rec["launches"]),
-            "algorithmic_bytes_per_px": round(bpp, 2), "px_per_launch": round(rec["px"] / rec["launches"])}
+    out = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+           "avg_launch_ms": round(rec["ms"] / rec["launches"], 4), "launches": rec["launches"],
+           "algorithmic_bytes_per_launch": round(bpp * rec["px"] / rec["launches"]),
+           "algorithmic_bytes_per_px": round(bpp, 2), "px_per_launch": round(rec["px"] / rec["launches"])}
+    if name in ("blur_v", "blur_h_solve") and winsize_taps:
+        # informational: these two kernels are bound by packed-FP32 issue, not by HBM.  FIR work = 5 planes x
+        # (3 lane-ops per tap pair + 1) per pixel; peak = the v_pk_mul_f32 rate measured on this GPU
+        # (profiles/r01_ubench_valu.txt, 8 waves/SIMD)
+        lane_ops = 5 * (3 * winsize_taps + 1) * rec["px"]
+        tl = lane_ops / (rec["ms"] * 1e-3) / 1e12
+        out["valu"] = {"achieved": round(tl, 2), "peak": VALU_PK_PEAK_TLOPS, "unit": "T lane-ops/s (fp32, unfused)",
+                       "frac": round(tl / VALU_PK_PEAK_TLOPS, 4)}
+    return out
 
 
 def cpu_baseline(sample, params):
@@ -226,7 +236,8 @@ def main():
         # with use_dog the Farneback inputs are the uint8 DOG images (1 B/px), not the f32 level images
         fb_esz = 1 if reg.use_dog else esz
         tps = pmc_traffic(args.workload) if not args.size and not args.fused and not args.no_dog else {}
-        kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz, args.steps, tps)
+        win = reg.overlap - (1 - reg.overlap % 2)
+        kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz, args.steps, tps, win // 2)
                    for k, v in prof.items()}
         kernels = {k: v for k, v in kernels.items() if v}
         total_kernel_ms = sum(v["ms"] for v in prof.values())
