@@ -1,0 +1,34 @@
+#!/bin/bash
+# Per-kernel SQ counters (separate --pmc passes) for the Farneback kernels: bash tools/sq_counters.sh [workload]
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+WL=${1:-cfg2}
+OUT=gpurun_out/sq_$WL
+rm -rf $OUT; mkdir -p $OUT
+CMD="python3 bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --no-variants"
+i=0
+for grp in "SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
+           "SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_ADDR_CONFLICT" \
+           "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_IFETCH" \
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp -d $OUT/p$i --output-format csv -- $CMD > /dev/null 2> $OUT/p$i.err
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob(out + "/p*/*/*_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"]
+        key = next((k for k in ("fb_blur_h_solve", "fb_blur_v", "fb_polyexp_m0", "dog_cols_diff", "dog_rows") if k in n), None)
+        if key:
+            acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
+for k, d in acc.items():
+    print(k)
+    for c in sorted(d):
+        print(f"   {c:34s} {d[c]:.4g}")
+PY
