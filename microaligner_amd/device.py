@@ -324,6 +324,7 @@ class Context:
 
 
 _contexts = {}
+_contexts_lock = threading.Lock()
 _tls = threading.local()
 
 
@@ -361,14 +362,17 @@ def get_context(device=None):
         if cur is not None:
             return cur
         device = default_device()
-    ctx = _contexts.get(device)
-    if ctx is None:
-        n = C.c_int()
-        lib = L.load()
-        lib.ma_device_count(C.byref(n))
-        if n.value > 0:
-            device = device % n.value
-        ctx = _contexts[device] = Context(device)
+    with _contexts_lock:
+        ctx = _contexts.get(device)
+        if ctx is None:
+            n = C.c_int()
+            lib = L.load()
+            lib.ma_device_count(C.byref(n))
+            if n.value > 0:
+                device = device % n.value
+            ctx = _contexts.get(device)
+            if ctx is None:
+                ctx = _contexts[device] = Context(device)
     return ctx
 
 
