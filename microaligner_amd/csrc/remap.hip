@@ -230,6 +230,68 @@ __global__ __launch_bounds__(256) void window_max_kernel(const float2* __restric
     }
 }
 
+// Window maxima from non-overlapping cells (T > 2*ov): along each axis the window borders k*T - ov and k*T + ov cut
+// the image into segments  zone_k = [k*T - ov, k*T + ov)  (index 2k) and  core_k = [k*T + ov, (k+1)*T - ov)
+// (index 2k+1); window t is the union of segments 2t, 2t+1, 2t+2, so every flow value is read once (the banded
+// kernel above reads the overlaps 1.44x at tile 1000 / overlap 100).
+// cell_max_kernel: grid (x segments, row bands of the y segments); cellkeys zero-initialised.
+constexpr int CM_ROWS = 64;
+__device__ __forceinline__ void seg_range(int s, int T, int ov, int len, int& a, int& b)
+{
+    const int k = s >> 1;
+    if (s & 1) { a = k * T + ov; b = (k + 1) * T - ov; }
+    else { a = k * T - ov; b = k * T + ov; }
+    a = max(a, 0); b = min(b, len);
+}
+__global__ __launch_bounds__(256) void cell_max_kernel(const float2* __restrict__ f1, const float2* __restrict__ f2,
+                                                       MaTiling g, int nsegx, unsigned* __restrict__ cellkeys)
+{
+    const int bz = (2 * g.ov + CM_ROWS - 1) / CM_ROWS, bc = (g.T - 2 * g.ov + CM_ROWS - 1) / CM_ROWS;
+    const int per = blockIdx.y / (bz + bc), r = blockIdx.y - per * (bz + bc);
+    const int segy = r < bz ? 2 * per : 2 * per + 1, band = r < bz ? r : r - bz;
+    int ya, yb, xa, xb;
+    seg_range(segy, g.T, g.ov, g.H, ya, yb);
+    seg_range(blockIdx.x, g.T, g.ov, g.W, xa, xb);
+    // zone 0 starts at -ov: bands are counted from the unclipped segment start so that they tile it exactly
+    const int y0 = (segy & 1 ? (segy >> 1) * g.T + g.ov : (segy >> 1) * g.T - g.ov) + band * CM_ROWS;
+    ya = max(ya, y0); yb = min(yb, y0 + CM_ROWS);
+    if (ya >= yb || xa >= xb) return;
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (int yy = ya + (threadIdx.x >> 6); yy < yb; yy += 4)
+        for (int xx = xa + (threadIdx.x & 63); xx < xb; xx += 64) {
+            const float2 a = f1[(size_t)yy * g.W + xx], b = f2[(size_t)yy * g.W + xx];
+            m1 = fmaxf(m1, fmaxf(a.x, a.y));
+            m2 = fmaxf(m2, fmaxf(b.x, b.y));
+        }
+    for (int off = 32; off > 0; off >>= 1) {
+        m1 = fmaxf(m1, __shfl_down(m1, off));
+        m2 = fmaxf(m2, __shfl_down(m2, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        unsigned* c = cellkeys + ((size_t)segy * nsegx + blockIdx.x) * 2;
+        atomicMax(&c[0], f2key(m1));
+        atomicMax(&c[1], f2key(m2));
+    }
+}
+// one thread per window: max over its 3 x 3 cells; zero padding takes part in numpy's .max()
+__global__ void window_from_cells_kernel(const unsigned* __restrict__ cellkeys, MaTiling g, int nsegx,
+                                         unsigned* __restrict__ maxkeys)
+{
+    const int widx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (widx >= g.ntx * g.nty) return;
+    const int ty = widx / g.ntx, tx = widx - ty * g.ntx;
+    const int oy = ty * g.T - g.ov, ox = tx * g.T - g.ov;
+    const bool padded = oy < 0 || ox < 0 || oy + g.Ph > g.H || ox + g.Pw > g.W;
+    unsigned k1 = padded ? f2key(0.f) : 0u, k2 = k1;
+    for (int j = 0; j < 3; j++)
+        for (int i = 0; i < 3; i++) {
+            const unsigned* c = cellkeys + ((size_t)(2 * ty + j) * nsegx + 2 * tx + i) * 2;
+            k1 = max(k1, c[0]); k2 = max(k2, c[1]);
+        }
+    maxkeys[widx * 2] = k1;
+    maxkeys[widx * 2 + 1] = k2;
+}
+
 constexpr int MERGE_ROWS = 8;
 __global__ __launch_bounds__(256) void merge_flows_kernel(const float2* __restrict__ f1, const float2* __restrict__ f2,
                                                           MaTiling g, const unsigned* __restrict__ maxkeys,
@@ -422,12 +484,24 @@ int ma_merge_flows_tiled(ma_ctx* ctx, const float* flow1, const float* flow2, in
     MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
     MA_HIP(hipSetDevice(ctx->device));
     const int nwin = g.ntx * g.nty;
-    MA_TRY(ma_dconst_reserve(ctx, (size_t)nwin * 2 * sizeof(unsigned)));
+    const bool cells = tile > 0 && overlap > 0 && tile > 2 * overlap;
+    const int nsegx = 2 * g.ntx + 1, nsegy = 2 * g.nty + 1;
+    const size_t ncell = cells ? (size_t)nsegx * nsegy : 0;
+    MA_TRY(ma_dconst_reserve(ctx, ((size_t)nwin + ncell) * 2 * sizeof(unsigned)));
     unsigned* maxes = (unsigned*)ctx->dconst;
+    unsigned* cellkeys = maxes + (size_t)nwin * 2;
     MaProfScope ps(ctx, MA_K_MERGE, (double)H * W);
-    MA_HIP(hipMemsetAsync(maxes, 0, (size_t)nwin * 2 * sizeof(unsigned), ctx->stream));
-    hipLaunchKernelGGL(window_max_kernel, dim3(nwin, (g.Ph + WM_ROWS - 1) / WM_ROWS), dim3(256), 0, ctx->stream,
-                       (const float2*)flow1, (const float2*)flow2, g, maxes);
+    MA_HIP(hipMemsetAsync(maxes, 0, ((size_t)nwin + ncell) * 2 * sizeof(unsigned), ctx->stream));
+    if (cells) {
+        const int bands = (2 * overlap + CM_ROWS - 1) / CM_ROWS + (tile - 2 * overlap + CM_ROWS - 1) / CM_ROWS;
+        hipLaunchKernelGGL(cell_max_kernel, dim3(nsegx, (g.nty + 1) * bands), dim3(256), 0, ctx->stream,
+                           (const float2*)flow1, (const float2*)flow2, g, nsegx, cellkeys);
+        hipLaunchKernelGGL(window_from_cells_kernel, dim3((nwin + 255) / 256), dim3(256), 0, ctx->stream, cellkeys, g,
+                           nsegx, maxes);
+    } else {
+        hipLaunchKernelGGL(window_max_kernel, dim3(nwin, (g.Ph + WM_ROWS - 1) / WM_ROWS), dim3(256), 0, ctx->stream,
+                           (const float2*)flow1, (const float2*)flow2, g, maxes);
+    }
     hipLaunchKernelGGL(merge_flows_kernel, dim3((W + 255) / 256, (H + MERGE_ROWS - 1) / MERGE_ROWS), dim3(256), 0, ctx->stream, (const float2*)flow1,
                        (const float2*)flow2, g, maxes, (float2*)out);
     MA_HIP(hipGetLastError());

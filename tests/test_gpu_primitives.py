@@ -164,6 +164,19 @@ def test_merge_flows_bit_exact_including_window_shortcuts(ctx):
     assert np.array_equal(ctx.merge_flows(ctx.asdevice(f1), ctx.asdevice(z), T, ov).numpy(), RO.merge_flows(f1, z, T, ov))
 
 
+@pytest.mark.parametrize("shape,T,ov", [((333, 297), 100, 15), ((260, 410), 64, 32), ((200, 200), 50, 30),
+                                         ((150, 700), 128, 1), ((90, 80), 100, 20)])
+def test_merge_flows_geometries(ctx, shape, T, ov):
+    """Cell-based window maxima (T > 2*ov), the banded fallback (T <= 2*ov) and the untiled branch."""
+    h, w = shape
+    f1, f2 = rand_flow(h, w, 3, 2.5), rand_flow(h, w, 4, 1.5)
+    f1[: h // 3, : w // 2] = 0
+    f2[h // 2:, w // 3:] = -np.abs(f2[h // 2:, w // 3:])
+    f2[h // 2:, w // 2:] = 0
+    got = ctx.merge_flows(ctx.asdevice(f1), ctx.asdevice(f2), T, ov).numpy()
+    assert np.array_equal(got, RO.merge_flows(f1, f2, T, ov))
+
+
 def test_merge_two_flows_function(ctx):
     from microaligner_amd import merge_two_flows
     f1, f2 = rand_flow(90, 80, 6, 2.0), rand_flow(90, 80, 7, 2.0)
