@@ -142,8 +142,9 @@ class Daisy:
         return des
 
 
-def knn2(query: np.ndarray, train: np.ndarray, block: int = 2048):
-    """Exact two nearest neighbours (L2) of every query row in `train`: (idx (n,2), dist (n,2))."""
+def knn2(query: np.ndarray, train: np.ndarray, block: int = 1024):
+    """Exact two nearest neighbours (L2) of every query row in `train`: (idx (n,2), dist (n,2)).  Needs at least
+    two train rows.  Two arg-min passes per block (the first minimum is masked for the second)."""
     q = np.ascontiguousarray(query, np.float32)
     t = np.ascontiguousarray(train, np.float32)
     tn = np.einsum("ij,ij->i", t, t)
@@ -152,11 +153,15 @@ def knn2(query: np.ndarray, train: np.ndarray, block: int = 2048):
     for s in range(0, len(q), block):
         qb = q[s:s + block]
         d2 = np.einsum("ij,ij->i", qb, qb)[:, None] + tn[None, :] - 2.0 * (qb @ t.T)
-        part = np.argpartition(d2, 1, axis=1)[:, :2]
-        dd = np.take_along_axis(d2, part, axis=1)
-        order = np.argsort(dd, axis=1)
-        idx[s:s + block] = np.take_along_axis(part, order, axis=1)
-        dist[s:s + block] = np.sqrt(np.maximum(np.take_along_axis(dd, order, axis=1), 0))
+        rows = np.arange(len(qb))
+        i0 = d2.argmin(1)
+        v0 = d2[rows, i0].copy()
+        d2[rows, i0] = np.inf
+        i1 = d2.argmin(1)
+        v1 = d2[rows, i1]
+        idx[s:s + block, 0], idx[s:s + block, 1] = i0, i1
+        dist[s:s + block, 0] = np.sqrt(np.maximum(v0, 0))
+        dist[s:s + block, 1] = np.sqrt(np.maximum(v1, 0))
     return idx, dist
 
 
