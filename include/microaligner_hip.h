@@ -183,6 +183,18 @@ int ma_normalize_minmax_u8(ma_ctx* ctx, const void* src, int dtype, size_t n, ui
 int ma_warp_affine(ma_ctx* ctx, const void* src, int dtype, int h, int w, const double* inverse_3x3_host,
                    void* dst);
 
+/* Producer/consumer variants that keep the min / max of an image on the device.  dog() starts with
+ * cv2.normalize(img, 0, 1, NORM_MINMAX) (optflow_registrator.py:259): when the image was just written by a warp
+ * (optflow_registrator.py:113,125 via Warper.warp) or by cv2.pyrDown (:194), the producing kernel can reduce its
+ * own output -- ma_warp_tiled_minmax / ma_pyr_down_minmax store (min, max) as two floats at minmax_dev (device
+ * memory) -- and ma_dog_u8_minmax takes them instead of reading the image once more.  Results are identical to
+ * the plain entry points. */
+int ma_warp_tiled_minmax(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile,
+                         int overlap, void* out, float* minmax_dev);
+int ma_pyr_down_minmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst, float* minmax_dev);
+int ma_dog_u8_minmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma,
+                     const float* src_minmax_dev, uint8_t* dst, int* src_max_is_zero_host);
+
 /* cv2.warpAffine(src, M, dsize=(dw, dh)) with the default flags (INTER_LINEAR, BORDER_CONSTANT 0), the call of
  * FeatureRegistrator.transform_img (feature_reg/feature_registrator.py:128-132) for images up to 32000 px.
  * m2x3_host: the FORWARD 2x3 matrix (6 doubles, row major) exactly as passed to cv2.warpAffine; it is inverted in

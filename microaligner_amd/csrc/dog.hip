@@ -393,6 +393,13 @@ constexpr int DC_NW = 4;  // column pass: 64 columns x 4*R rows per block; R = 2
 
 } // namespace
 
+int ma_launch_minmax_final(ma_ctx* ctx, const float* part, int nparts, float* out2)
+{
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, nparts, out2);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
 extern "C" {
 
 int ma_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn_host, double* mx_host)
@@ -404,8 +411,8 @@ int ma_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn_host
     return minmax_host(ctx, src, dtype, n, mn_host, mx_host);
 }
 
-int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst,
-              int* src_max_is_zero_host)
+static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst,
+                       int* src_max_is_zero_host, const float* src_minmax_dev)
 {
     MA_REQUIRE(ctx && src && dst, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
@@ -449,7 +456,11 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
     MA_REQUIRE((h + DR - 1) / DR <= 65535, "image too tall");
 
     MaProfScope ps(ctx, MA_K_DOG, (double)n);
-    MA_TRY(launch_minmax(ctx, src, dtype, n, part, sc->mm_src));
+    if (src_minmax_dev) {  // the producer of `src` already reduced it
+        MA_HIP(hipMemcpyAsync(sc->mm_src, src_minmax_dev, 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        MA_TRY(launch_minmax(ctx, src, dtype, n, part, sc->mm_src));
+    }
     hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc);
     {
         dim3 grid((w + 255) / 256, (h + DR - 1) / DR), block(256);
@@ -482,6 +493,19 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
         *src_max_is_zero_host = *(int*)ctx->pinned;
     }
     return MA_OK;
+}
+
+int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst,
+              int* src_max_is_zero_host)
+{
+    return dog_u8_impl(ctx, src, dtype, h, w, low_sigma, high_sigma, dst, src_max_is_zero_host, nullptr);
+}
+
+int ma_dog_u8_minmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma,
+                     const float* src_minmax_dev, uint8_t* dst, int* src_max_is_zero_host)
+{
+    MA_REQUIRE(src_minmax_dev, "NULL argument");
+    return dog_u8_impl(ctx, src, dtype, h, w, low_sigma, high_sigma, dst, src_max_is_zero_host, src_minmax_dev);
 }
 
 int ma_max_project(ma_ctx* ctx, const void* planes, int dtype, int nz, size_t n, void* dst)

@@ -275,6 +275,26 @@ __device__ __forceinline__ void d_sym_fir_slide_pk(const float* __restrict__ col
     }
 }
 
+// Block-wide (min, max) of per-thread values -> part[0], part[1] (thread 0 writes).  All threads of the block must
+// call it; blocks of up to 1024 threads.
+__device__ __forceinline__ void d_block_minmax(float lo, float hi, float* part)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fminf(lo, __shfl_down(lo, off));
+        hi = fmaxf(hi, __shfl_down(hi, off));
+    }
+    __shared__ float s_lo[16], s_hi[16];
+    const int nw = (blockDim.x * blockDim.y * blockDim.z + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < nw; k++) { lo = fminf(lo, s_lo[k]); hi = fmaxf(hi, s_hi[k]); }
+        part[0] = lo; part[1] = hi;
+    }
+}
+// folds nparts (min, max) pairs on the device into out2[0..1] (dog.hip); stream ordered
+int ma_launch_minmax_final(ma_ctx* ctx, const float* part, int nparts, float* out2);
+
 // XCD-aware work mapping (speed only, never correctness).  Workgroups of a 1-D grid are dealt round-robin to the
 // 8 XCDs (block b -> XCD b % 8), each with its own 4 MiB L2.  Stencil blocks that share a halo should therefore
 // be consecutive *within one XCD*: block b takes work item (b % 8) * ceil(N/8) + b / 8, so every XCD walks a

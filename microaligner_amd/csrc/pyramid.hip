@@ -42,11 +42,12 @@ __device__ __forceinline__ T pyr_down_px(const T* __restrict__ src, int h, int w
 // A thread produces the destination pair (2p, 2p+1) of row y from source columns 4p-2 .. 4p+4: one 2-vector, one
 // 4-vector and one scalar load per source row instead of ten scalar loads (vec: w % 4 == 0, so the vectors are
 // aligned).  Pairs that touch the left/right border and everything when !vec take the per-pixel path.
-// PD_ROWS destination rows per thread: their 2*PD_ROWS + 3 source rows are loaded once (all loads issued up front)
+// PD_ROWS destination rows per thread: their 2*PD_ROWS + 3 source rows are loaded once (all loads issued up front).
+// MM: also reduce (min, max) of the block's outputs into part[2 * block] (see warp_tiled_kernel).
 constexpr int PD_ROWS = 4;
-template <typename T>
+template <typename T, bool MM>
 __global__ __launch_bounds__(256) void pyr_down_kernel(const T* __restrict__ src, int h, int w, T* __restrict__ dst,
-                                                       int dh, int dw, int vec)
+                                                       int dh, int dw, int vec, float* __restrict__ part)
 {
     using A = typename PyrAcc<T>::type;
     using V2 = typename PyrVec<T>::v2;
@@ -54,43 +55,53 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const T* __restrict__ src
     constexpr int NR = 2 * PD_ROWS + 3;
     const int p = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * PD_ROWS;
     const int x0 = 2 * p;
-    if (x0 >= dw) return;
-    if (!vec || p == 0 || 4 * p + 4 >= w || x0 + 1 >= dw) {
-        for (int r = 0; r < PD_ROWS && y0 + r < dh; r++) {
-            T* drow = dst + (size_t)(y0 + r) * dw;
-            drow[x0] = pyr_down_px<T>(src, h, w, x0, y0 + r);
-            if (x0 + 1 < dw) drow[x0 + 1] = pyr_down_px<T>(src, h, w, x0 + 1, y0 + r);
+    float lo = INFINITY, hi = -INFINITY;
+    auto put = [&](T* at, T v) {
+        *at = v;
+        if (MM) { lo = fminf(lo, (float)v); hi = fmaxf(hi, (float)v); }
+    };
+    if (x0 < dw) {
+        if (!vec || p == 0 || 4 * p + 4 >= w || x0 + 1 >= dw) {
+            for (int r = 0; r < PD_ROWS && y0 + r < dh; r++) {
+                T* drow = dst + (size_t)(y0 + r) * dw;
+                put(drow + x0, pyr_down_px<T>(src, h, w, x0, y0 + r));
+                if (x0 + 1 < dw) put(drow + x0 + 1, pyr_down_px<T>(src, h, w, x0 + 1, y0 + r));
+            }
+        } else {
+            V2 l[NR];
+            V4 m[NR];
+            T e[NR];
+#pragma unroll
+            for (int k = 0; k < NR; k++) {
+                // rows past the last destination row of a partial group are clamped (loaded, not used)
+                const T* s = src + (size_t)d_reflect101(min(2 * y0 + k - 2, 2 * (dh - 1) + 2), h) * w + 4 * p;
+                l[k] = *reinterpret_cast<const V2*>(s - 2);
+                m[k] = *reinterpret_cast<const V4*>(s);
+                e[k] = s[4];
+            }
+            A ra[NR], rb[NR];
+#pragma unroll
+            for (int k = 0; k < NR; k++) {
+                const A c0 = (A)l[k].x, c1 = (A)l[k].y, c2 = (A)m[k].x, c3 = (A)m[k].y, c4 = (A)m[k].z, c5 = (A)m[k].w, c6 = (A)e[k];
+                ra[k] = c2 * 6 + (c1 + c3) * 4 + c0 + c4;
+                rb[k] = c4 * 6 + (c3 + c5) * 4 + c2 + c6;
+            }
+#pragma unroll
+            for (int r = 0; r < PD_ROWS; r++) {
+                if (y0 + r >= dh) break;
+                const int k = 2 * r;
+                const T oa = pyr_down_finish<T>(ra[k + 2] * 6 + (ra[k + 1] + ra[k + 3]) * 4 + ra[k] + ra[k + 4]);
+                const T ob = pyr_down_finish<T>(rb[k + 2] * 6 + (rb[k + 1] + rb[k + 3]) * 4 + rb[k] + rb[k + 4]);
+                T* drow = dst + (size_t)(y0 + r) * dw;
+                if ((dw & 1) == 0) {
+                    V2 o; o.x = oa; o.y = ob;
+                    *reinterpret_cast<V2*>(drow + x0) = o;
+                    if (MM) { lo = fminf(lo, fminf((float)oa, (float)ob)); hi = fmaxf(hi, fmaxf((float)oa, (float)ob)); }
+                } else { put(drow + x0, oa); put(drow + x0 + 1, ob); }
+            }
         }
-        return;
     }
-    V2 l[NR];
-    V4 m[NR];
-    T e[NR];
-#pragma unroll
-    for (int k = 0; k < NR; k++) {
-        // rows past the last destination row of a partial group are clamped (loaded, not used)
-        const T* s = src + (size_t)d_reflect101(min(2 * y0 + k - 2, 2 * (dh - 1) + 2), h) * w + 4 * p;
-        l[k] = *reinterpret_cast<const V2*>(s - 2);
-        m[k] = *reinterpret_cast<const V4*>(s);
-        e[k] = s[4];
-    }
-    A ra[NR], rb[NR];
-#pragma unroll
-    for (int k = 0; k < NR; k++) {
-        const A c0 = (A)l[k].x, c1 = (A)l[k].y, c2 = (A)m[k].x, c3 = (A)m[k].y, c4 = (A)m[k].z, c5 = (A)m[k].w, c6 = (A)e[k];
-        ra[k] = c2 * 6 + (c1 + c3) * 4 + c0 + c4;
-        rb[k] = c4 * 6 + (c3 + c5) * 4 + c2 + c6;
-    }
-#pragma unroll
-    for (int r = 0; r < PD_ROWS; r++) {
-        if (y0 + r >= dh) break;
-        const int k = 2 * r;
-        const T oa = pyr_down_finish<T>(ra[k + 2] * 6 + (ra[k + 1] + ra[k + 3]) * 4 + ra[k] + ra[k + 4]);
-        const T ob = pyr_down_finish<T>(rb[k + 2] * 6 + (rb[k + 1] + rb[k + 3]) * 4 + rb[k] + rb[k + 4]);
-        T* drow = dst + (size_t)(y0 + r) * dw;
-        if ((dw & 1) == 0) { V2 o; o.x = oa; o.y = ob; *reinterpret_cast<V2*>(drow + x0) = o; }
-        else { drow[x0] = oa; drow[x0 + 1] = ob; }
-    }
+    if (MM) d_block_minmax(lo, hi, part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
 }
 
 // horizontally upsampled value of one source row at destination column X (two channels)
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256) void pyr_up_flow_kernel(const float2* __restri
 
 extern "C" {
 
-int ma_pyr_down(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst)
+static int pyr_down_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst, float* minmax_dev)
 {
     MA_REQUIRE(ctx && src && dst, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
@@ -195,14 +206,35 @@ int ma_pyr_down(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst
     const int dh = (h + 1) / 2, dw = (w + 1) / 2;
     MA_REQUIRE(dh <= 65535, "image too tall");
     MA_HIP(hipSetDevice(ctx->device));
-    MaProfScope ps(ctx, MA_K_PYR_DOWN, (double)h * w);
     dim3 grid(((dw + 1) / 2 + 255) / 256, (dh + PD_ROWS - 1) / PD_ROWS), block(256);
+    const size_t nblk = (size_t)grid.x * grid.y;
+    float* part = nullptr;
+    if (minmax_dev) {
+        MA_TRY(ma_ws_reserve(ctx, nblk * 2 * sizeof(float)));
+        part = (float*)ctx->ws;
+    }
+    MaProfScope ps(ctx, MA_K_PYR_DOWN, (double)h * w);
     const int vec = (w % 4 == 0) && ((size_t)src % 16 == 0) && ((size_t)dst % 8 == 0);
-    if (dtype == MA_U8) hipLaunchKernelGGL((pyr_down_kernel<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)src, h, w, (uint8_t*)dst, dh, dw, vec);
-    else if (dtype == MA_U16) hipLaunchKernelGGL((pyr_down_kernel<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)src, h, w, (uint16_t*)dst, dh, dw, vec);
-    else hipLaunchKernelGGL((pyr_down_kernel<float>), grid, block, 0, ctx->stream, (const float*)src, h, w, (float*)dst, dh, dw, vec);
+#define MA_PD(T) do { if (part) hipLaunchKernelGGL((pyr_down_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)src, h, w, (T*)dst, dh, dw, vec, part); \
+                      else hipLaunchKernelGGL((pyr_down_kernel<T, false>), grid, block, 0, ctx->stream, (const T*)src, h, w, (T*)dst, dh, dw, vec, part); } while (0)
+    if (dtype == MA_U8) MA_PD(uint8_t);
+    else if (dtype == MA_U16) MA_PD(uint16_t);
+    else MA_PD(float);
+#undef MA_PD
     MA_HIP(hipGetLastError());
+    if (part) MA_TRY(ma_launch_minmax_final(ctx, part, (int)nblk, minmax_dev));
     return MA_OK;
+}
+
+int ma_pyr_down(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst)
+{
+    return pyr_down_impl(ctx, src, dtype, h, w, dst, nullptr);
+}
+
+int ma_pyr_down_minmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst, float* minmax_dev)
+{
+    MA_REQUIRE(minmax_dev, "NULL argument");
+    return pyr_down_impl(ctx, src, dtype, h, w, dst, minmax_dev);
 }
 
 int ma_pyr_up_flow(ma_ctx* ctx, const float* src, int h, int w, float scale, float* dst, int dh, int dw)

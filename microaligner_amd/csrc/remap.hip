@@ -162,27 +162,38 @@ __device__ __forceinline__ T warp_tiled_px(const T* __restrict__ img, const MaTi
 // WARP_ROWS rows per thread: the flow loads of all rows are issued before the first gather, the gathers of all
 // rows before the first store -- 8 rows in flight per thread run 1.4x faster than one (measured, profiles/r01_notes.md)
 constexpr int WARP_ROWS = 8;
-template <typename T>
+// MM: also reduce (min, max) of the block's output pixels into part[2 * block] (input conditioning of a following
+// dog(): the consumer then skips its own pass over the image)
+template <typename T, bool MM>
 __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ img, MaTiling g,
-                                                         const float2* __restrict__ flow, T* __restrict__ out)
+                                                         const float2* __restrict__ flow, T* __restrict__ out,
+                                                         float* __restrict__ part)
 {
     constexpr int WR = WARP_ROWS;
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * WR;
-    if (x >= g.W) return;
-    const int ox = g.T > 0 ? (x / g.T) * g.T - g.ov : 0;
-    float2 f[WR];
+    const bool xin = x < g.W;
+    if (!MM && !xin) return;
+    float lo = INFINITY, hi = -INFINITY;
+    if (xin) {
+        const int ox = g.T > 0 ? (x / g.T) * g.T - g.ov : 0;
+        float2 f[WR];
 #pragma unroll
-    for (int r = 0; r < WR; r++) f[r] = flow[(size_t)min(y0 + r, g.H - 1) * g.W + x];
-    T res[WR];
+        for (int r = 0; r < WR; r++) f[r] = flow[(size_t)min(y0 + r, g.H - 1) * g.W + x];
+        T res[WR];
 #pragma unroll
-    for (int r = 0; r < WR; r++) {
-        const int y = y0 + r;
-        const int oy = g.T > 0 ? (y / g.T) * g.T - g.ov : 0;
-        res[r] = warp_tiled_px<T>(img, g, f[r], x, min(y, g.H - 1), oy, ox);
+        for (int r = 0; r < WR; r++) {
+            const int y = y0 + r;
+            const int oy = g.T > 0 ? (y / g.T) * g.T - g.ov : 0;
+            res[r] = warp_tiled_px<T>(img, g, f[r], x, min(y, g.H - 1), oy, ox);
+        }
+#pragma unroll
+        for (int r = 0; r < WR; r++)
+            if (y0 + r < g.H) {
+                out[(size_t)(y0 + r) * g.W + x] = res[r];
+                if (MM) { lo = fminf(lo, (float)res[r]); hi = fmaxf(hi, (float)res[r]); }
+            }
     }
-#pragma unroll
-    for (int r = 0; r < WR; r++)
-        if (y0 + r < g.H) out[(size_t)(y0 + r) * g.W + x] = res[r];
+    if (MM) d_block_minmax(lo, hi, part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
 }
 
 // ---- flow merge ---------------------------------------------------------------------------------
@@ -396,8 +407,8 @@ int ma_warp_affine_cv(ma_ctx* ctx, const void* src, int dtype, int sh, int sw, c
     return MA_OK;
 }
 
-int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile, int overlap,
-                  void* out)
+static int warp_tiled_impl(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile, int overlap,
+                           void* out, float* minmax_dev)
 {
     MA_REQUIRE(ctx && img && flow && out, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
@@ -406,14 +417,37 @@ int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const f
     MaTiling g = ma_make_tiling(H, W, tile, overlap);
     MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
     MA_HIP(hipSetDevice(ctx->device));
-    MaProfScope ps(ctx, MA_K_WARP, (double)H * W);
     dim3 grid((W + 255) / 256, (H + WARP_ROWS - 1) / WARP_ROWS), block(256);
+    const size_t nblk = (size_t)grid.x * grid.y;
+    float* part = nullptr;
+    if (minmax_dev) {
+        MA_TRY(ma_ws_reserve(ctx, nblk * 2 * sizeof(float)));
+        part = (float*)ctx->ws;
+    }
+    MaProfScope ps(ctx, MA_K_WARP, (double)H * W);
     const float2* f = (const float2*)flow;
-    if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)img, g, f, (uint8_t*)out);
-    else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)img, g, f, (uint16_t*)out);
-    else hipLaunchKernelGGL((warp_tiled_kernel<float>), grid, block, 0, ctx->stream, (const float*)img, g, f, (float*)out);
+#define MA_WARP(T) do { if (part) hipLaunchKernelGGL((warp_tiled_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part); \
+                        else hipLaunchKernelGGL((warp_tiled_kernel<T, false>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part); } while (0)
+    if (dtype == MA_U8) MA_WARP(uint8_t);
+    else if (dtype == MA_U16) MA_WARP(uint16_t);
+    else MA_WARP(float);
+#undef MA_WARP
     MA_HIP(hipGetLastError());
+    if (part) MA_TRY(ma_launch_minmax_final(ctx, part, (int)nblk, minmax_dev));
     return MA_OK;
+}
+
+int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile, int overlap,
+                  void* out)
+{
+    return warp_tiled_impl(ctx, img, dtype, H, W, flow, tile, overlap, out, nullptr);
+}
+
+int ma_warp_tiled_minmax(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile,
+                         int overlap, void* out, float* minmax_dev)
+{
+    MA_REQUIRE(minmax_dev, "NULL argument");
+    return warp_tiled_impl(ctx, img, dtype, H, W, flow, tile, overlap, out, minmax_dev);
 }
 
 // ---- page-warp driver ---------------------------------------------------------------------
@@ -462,9 +496,9 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
     for (int i = 0; i < n_pages; i++) {
         Slot& s = slots[i % ns];  // stream order keeps the slot's buffers safe: copy-in waits for the previous copy-out
         PG_HIP(hipMemcpyAsync(s.din, pages_host[i], nb, hipMemcpyHostToDevice, s.st));
-        if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t>), grid, block, 0, s.st, (const uint8_t*)s.din, g, f, (uint8_t*)s.dout);
-        else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t>), grid, block, 0, s.st, (const uint16_t*)s.din, g, f, (uint16_t*)s.dout);
-        else hipLaunchKernelGGL((warp_tiled_kernel<float>), grid, block, 0, s.st, (const float*)s.din, g, f, (float*)s.dout);
+        if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t, false>), grid, block, 0, s.st, (const uint8_t*)s.din, g, f, (uint8_t*)s.dout, (float*)nullptr);
+        else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t, false>), grid, block, 0, s.st, (const uint16_t*)s.din, g, f, (uint16_t*)s.dout, (float*)nullptr);
+        else hipLaunchKernelGGL((warp_tiled_kernel<float, false>), grid, block, 0, s.st, (const float*)s.din, g, f, (float*)s.dout, (float*)nullptr);
         PG_HIP(hipGetLastError());
         PG_HIP(hipMemcpyAsync(out_host[i], s.dout, nb, hipMemcpyDeviceToHost, s.st));
     }

@@ -25,11 +25,14 @@ def _dt(dtype):
 class DeviceArray:
     """Dense row-major array living in HBM.  Freed back to the context's pool on `free()`/GC."""
 
-    __slots__ = ("ctx", "shape", "dtype", "ptr", "_nbytes_alloc", "_owner")
+    __slots__ = ("ctx", "shape", "dtype", "ptr", "_nbytes_alloc", "_owner", "minmax")
 
     def __init__(self, ctx, shape, dtype, ptr, nbytes_alloc, owner=True):
         self.ctx, self.shape, self.dtype, self.ptr = ctx, tuple(int(s) for s in shape), np.dtype(dtype), ptr
         self._nbytes_alloc, self._owner = nbytes_alloc, owner
+        # optional DeviceArray of two floats (min, max of this array), left by the kernel that produced it
+        # (Context.warp / pyr_down with minmax=True) for a following dog_u8; arrays are never modified in place
+        self.minmax = None
 
     @property
     def size(self):
@@ -208,14 +211,20 @@ class Context:
                                            dst.ptr))
         return dst
 
-    def warp(self, img, flow, tile, overlap):
-        """Warper.warp() (warper.py:37-53)."""
+    def warp(self, img, flow, tile, overlap, minmax=False):
+        """Warper.warp() (warper.py:37-53).  minmax=True also leaves the output's (min, max) on the device
+        (out.minmax) for a following dog_u8."""
         H, W = img.shape
         if flow.shape != (H, W, 2) or flow.dtype != np.float32:
             raise ValueError(f"flow must be float32 of shape {(H, W, 2)}, got {flow.dtype} {flow.shape}")
         out = self.empty((H, W), img.dtype)
-        L.check(self.lib.ma_warp_tiled(self.handle, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile),
-                                       int(overlap), out.ptr))
+        if minmax:
+            out.minmax = self.empty((2,), np.float32)
+            L.check(self.lib.ma_warp_tiled_minmax(self.handle, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile),
+                                                  int(overlap), out.ptr, out.minmax.ptr))
+        else:
+            L.check(self.lib.ma_warp_tiled(self.handle, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile),
+                                           int(overlap), out.ptr))
         return out
 
     def warp_pages(self, pages, flow, tile, overlap, out=None):
@@ -252,10 +261,14 @@ class Context:
                                               out.ptr))
         return out
 
-    def pyr_down(self, img):
+    def pyr_down(self, img, minmax=False):
         h, w = img.shape
         out = self.empty(((h + 1) // 2, (w + 1) // 2), img.dtype)
-        L.check(self.lib.ma_pyr_down(self.handle, img.ptr, _dt(img.dtype), h, w, out.ptr))
+        if minmax:
+            out.minmax = self.empty((2,), np.float32)
+            L.check(self.lib.ma_pyr_down_minmax(self.handle, img.ptr, _dt(img.dtype), h, w, out.ptr, out.minmax.ptr))
+        else:
+            L.check(self.lib.ma_pyr_down(self.handle, img.ptr, _dt(img.dtype), h, w, out.ptr))
         return out
 
     def pyr_up_flow(self, flow, dst_hw, scale=1.0):
@@ -277,8 +290,13 @@ class Context:
         h, w = img.shape
         out = self.empty((h, w), np.uint8)
         flag = C.c_int(0)
-        L.check(self.lib.ma_dog_u8(self.handle, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma),
-                                   out.ptr, C.byref(flag) if report_zero else None))
+        fl = C.byref(flag) if report_zero else None
+        if img.minmax is not None:   # the producing kernel already reduced the image
+            L.check(self.lib.ma_dog_u8_minmax(self.handle, img.ptr, _dt(img.dtype), h, w, int(low_sigma),
+                                              int(high_sigma), img.minmax.ptr, out.ptr, fl))
+        else:
+            L.check(self.lib.ma_dog_u8(self.handle, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma),
+                                       out.ptr, fl))
         return (out, bool(flag.value)) if report_zero else out
 
     def nmi_scores(self, a, b, chunk=0):

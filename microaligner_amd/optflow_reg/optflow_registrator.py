@@ -97,9 +97,9 @@ class OptFlowRegistrator:
         fc.muladd_fused = self.muladd_fused
 
     def _warp(self, img, flow):
-        self._warper.image = img
-        self._warper.flow = flow
-        return self._warper.warp()
+        # same call as Warper.warp() on device arrays; the kernel also leaves the output's min / max on the device,
+        # which the dog() of the warped image would otherwise have to reduce in a pass of its own
+        return self._ctx.warp(img, flow, self._warper.tile_size, self._warper.overlap, minmax=True)
 
     # -- the hot path -----------------------------------------------------------------------
     def register(self):
@@ -187,7 +187,7 @@ class OptFlowRegistrator:
             factor = 2 ** (lvl + 1)
             if full.shape[0] / factor < 100 or full.shape[1] / factor < 100:
                 break
-            cur = ctx.pyr_down(cur)
+            cur = ctx.pyr_down(cur, minmax=True)
             levels.append(cur)
             factors.append(factor)
         levels.reverse()

@@ -236,6 +236,29 @@ def test_dog_wide_rows_bit_exact(ctx, shape):
     assert np.array_equal(ctx.dog_u8(ctx.asdevice(img)).numpy(), O.dog(img, True))
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_producers_leave_min_max_for_dog(ctx, dtype):
+    """warp / pyr_down with minmax=True reduce their own output; dog_u8 then skips its pass and gives the same bits."""
+    img, _ = pair(333, 517, seed=8, dtype=dtype)
+    flow = rand_flow(333, 517, 9, 4.0)
+    d = ctx.asdevice(img)
+    w = ctx.warp(d, ctx.asdevice(flow), 100, 20, minmax=True)
+    wn = w.numpy()
+    assert np.array_equal(wn, ctx.warp(d, ctx.asdevice(flow), 100, 20).numpy())
+    assert tuple(w.minmax.numpy()) == (np.float32(wn.min()), np.float32(wn.max()))
+    assert np.array_equal(ctx.dog_u8(w).numpy(), O.dog(wn, True))
+    p = ctx.pyr_down(d, minmax=True)
+    pn = p.numpy()
+    assert np.array_equal(pn, O.pyr_down(img))
+    assert tuple(p.minmax.numpy()) == (np.float32(pn.min()), np.float32(pn.max()))
+    assert np.array_equal(ctx.dog_u8(p).numpy(), O.dog(pn, True))
+    tiny = ctx.pyr_down(ctx.asdevice(img[:3, :5].copy()), minmax=True)      # per-pixel path only
+    assert tuple(tiny.minmax.numpy()) == (np.float32(tiny.numpy().min()), np.float32(tiny.numpy().max()))
+    z = ctx.warp(ctx.asdevice(np.zeros((50, 60), dtype)), ctx.zeros((50, 60, 2), np.float32), 0, 0, minmax=True)
+    out, zero = ctx.dog_u8(z, report_zero=True)
+    assert zero and not out.numpy().any()
+
+
 def test_dog_special_cases_and_minmax(ctx):
     from microaligner_amd import OptFlowRegistrator
     reg = OptFlowRegistrator()
