@@ -187,7 +187,7 @@ class OptFlowRegistrator:
             factor = 2 ** (lvl + 1)
             if full.shape[0] / factor < 100 or full.shape[1] / factor < 100:
                 break
-            cur = ctx.pyr_down(cur, minmax=True)
+            cur = ctx.pyr_down(cur)
             levels.append(cur)
             factors.append(factor)
         levels.reverse()
