@@ -278,3 +278,32 @@ def test_cycle_chain_matches_the_oracle_pipeline():
         for c in range(C_):
             for z in range(Z_):
                 assert np.array_equal(aligned[cyc][c, z], RO.warp(cycles[cyc][c, z], flow, 200, 30))
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_register_random_configurations_match_the_oracle(seed):
+    """Seeded random shapes, dtypes and parameters (ragged sizes, tiny tiles, odd/even overlaps, with and without
+    DOG / full-resolution level, 1-4 iterations): flow, level decisions and warp equal the oracle orchestration."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(230, 520)), int(rng.integers(230, 520))
+    dtype = [np.uint8, np.uint16, np.float32][int(rng.integers(0, 3))]
+    tile = int(rng.integers(60, 200))
+    overlap = int(rng.integers(8, min(40, tile // 2)))
+    params = dict(num_pyr_lvl=int(rng.integers(0, 3)), num_iterations=int(rng.integers(1, 5)), tile_size=tile,
+                  overlap=overlap, use_full_res_img=bool(rng.integers(0, 2)), use_dog=bool(rng.integers(0, 2)))
+    if params["num_pyr_lvl"] == 0 or min(H, W) / 2 < 100:
+        params["use_full_res_img"] = True
+    if rng.integers(0, 4) == 0:
+        ref, mov = synthetic.make_unrelated_pair(H, W, seed, dtype)
+    else:
+        ref, mov = synthetic.make_pair(H, W, seed, dtype)
+    reg = make_reg(params)
+    reg.ref_img, reg.mov_img = ref, mov
+    flow = reg.register()
+    exp_flow, reports = RO.register(ref, mov, **params)
+    assert [r.accepted for r in reg.level_reports] == [r[3] for r in reports], params
+    assert np.array_equal(flow, exp_flow), params
+    w = Warper()
+    w.tile_size, w.overlap = tile, overlap
+    w.image, w.flow = mov, flow
+    assert np.array_equal(w.warp(), RO.warp(mov, exp_flow, tile, overlap)), params
