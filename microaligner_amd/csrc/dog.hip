@@ -389,7 +389,8 @@ void gaussian_kernel(int ksize, double sigma, std::vector<float>& k)
 
 int grid_for(size_t n) { size_t b = (n + 256 * 4 - 1) / (256 * 4); return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
 
-constexpr int DC_NW = 4;  // column pass: 64 columns x 4*R rows per block; R = 20 when r % 10 == 0 (no tail taps) else 16
+constexpr int DC_NW = 8;  // column pass: 64 columns x 8*R rows per block; R = 10 when r % 10 == 0 (no tail taps) else 16
+                          // (8 waves x 10 rows measured 2 % faster than 4 x 20, profiles/r01_notes.md)
 
 } // namespace
 
@@ -423,7 +424,7 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
     const int ksize = low_sigma * 4 * 2 + 1;  // optflow_registrator.py:262
     const int r = ksize / 2;
     const size_t lds_rows = 2 * ((size_t)DR * (256 + 2 * r) + 64) * sizeof(float);  // two copies (+ tail pad for the 16-byte reads)
-    const int DC_R = (r % 10 == 0) ? 20 : 16;
+    const int DC_R = (r % 10 == 0) ? 10 : 16;
     const size_t lds_cols = (size_t)(DC_NW * DC_R + 2 * r + 4) * 64 * sizeof(float);
     MA_REQUIRE(lds_rows <= 160 * 1024 && lds_cols <= 160 * 1024, "low_sigma too large for the LDS-staged DOG kernels");
 
@@ -476,8 +477,8 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
         }
 #undef MA_DOG_ROWS
     }
-    if (DC_R == 20)
-        hipLaunchKernelGGL((dog_cols_diff<20, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
+    if (DC_R == 10)
+        hipLaunchKernelGGL((dog_cols_diff<10, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
                            ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
     else
         hipLaunchKernelGGL((dog_cols_diff<16, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
