@@ -3,7 +3,7 @@
 //   merge_two_flows / _merge_flow_in_tiles   optflow_reg/optflow_registrator.py:37-47,217-233
 // Semantics: SURVEY.md Appendix A.2 -- coordinates quantised to 1/32 px with round-half-even,
 // u8 uses the 15-bit fixed-point table, u16/f32 use float weights summed left to right.
-// HBM-bound gathers: one destination pixel per thread, rows coalesced along x.
+// HBM-bound gathers, rows coalesced along x; the tiled kernels give a thread 8 rows and issue all their loads first.
 #include "ma_internal.h"
 
 #include <climits>
