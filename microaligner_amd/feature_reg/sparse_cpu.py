@@ -150,6 +150,23 @@ def knn2(query: np.ndarray, train: np.ndarray, block: int = 1024):
     tn = np.einsum("ij,ij->i", t, t)
     idx = np.empty((len(q), 2), np.int64)
     dist = np.empty((len(q), 2), np.float32)
+    with _blas_threads(16):
+        _knn2_blocks(q, t, tn, idx, dist, block)
+    return idx, dist
+
+
+def _blas_threads(n):
+    """Caps the BLAS thread pool for the block products (hundreds of spinning threads on a many-core host are
+    slower than 16 for these sizes, and pathological when the host is shared); a no-op without threadpoolctl."""
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=n, user_api="blas")
+    except Exception:
+        import contextlib
+        return contextlib.nullcontext()
+
+
+def _knn2_blocks(q, t, tn, idx, dist, block):
     for s in range(0, len(q), block):
         qb = q[s:s + block]
         d2 = np.einsum("ij,ij->i", qb, qb)[:, None] + tn[None, :] - 2.0 * (qb @ t.T)
@@ -162,7 +179,6 @@ def knn2(query: np.ndarray, train: np.ndarray, block: int = 1024):
         idx[s:s + block, 0], idx[s:s + block, 1] = i0, i1
         dist[s:s + block, 0] = np.sqrt(np.maximum(v0, 0))
         dist[s:s + block, 1] = np.sqrt(np.maximum(v1, 0))
-    return idx, dist
 
 
 def _fit_similarity(src: np.ndarray, dst: np.ndarray) -> Optional[np.ndarray]:

@@ -200,3 +200,35 @@ def register_cycle_chain(cycles: Sequence, ref_channel_ids=None, params: Optiona
         aligned.append(out)
         flows.append(flow.numpy())
     return aligned, flows
+
+
+def align_pairs(pairs: Sequence, feature_params: Optional[dict] = None, optflow_params: Optional[dict] = None,
+                gather: bool = True, lanes: int = 1):
+    """Two-stage alignment of independent (ref, mov) pairs -- mosaic tiles, BASELINE cfg5 -- sharded over the ranks:
+    feature-based affine initialisation (FeatureRegistrator, the pipeline's first stage, __main__.py:257-286),
+    transform_img_with_tmat, then the optical-flow refinement and warp (OptFlowRegistrator + Warper, :398-433).
+    Returns, per pair and in pair order on rank 0, (aligned moving image, 2x3 matrix, flow)."""
+    from . import FeatureRegistrator, OptFlowRegistrator, Warper, transform_img_with_tmat
+    feature_params, optflow_params = dict(feature_params or {}), dict(optflow_params or {})
+
+    def one(pair):
+        ref, mov = pair
+        freg = FeatureRegistrator()
+        freg.verbose = False
+        for k, v in feature_params.items():
+            setattr(freg, k, v)
+        freg.ref_img, freg.mov_img = ref, mov
+        t_mat = freg.register()
+        affine = transform_img_with_tmat(mov, ref.shape, t_mat)
+        oreg = OptFlowRegistrator()
+        oreg.verbose = False
+        for k, v in optflow_params.items():
+            setattr(oreg, k, v)
+        oreg.ref_img, oreg.mov_img = ref, affine
+        flow = oreg.register()
+        w = Warper()
+        w.tile_size, w.overlap = oreg.tile_size, oreg.overlap
+        w.image, w.flow = affine, flow
+        return w.warp(), t_mat, flow
+
+    return run_sharded(pairs, one, gather=gather, lanes=lanes)

@@ -195,6 +195,12 @@ def test_affine_init_then_optical_flow_refine():
     w.tile_size, w.overlap = 400, 60
     w.image, w.flow = affine, flow
     final = w.warp()
+    # the sharded driver composes the same two stages
+    from microaligner_amd import parallel
+    (final2, T2, flow2), = parallel.align_pairs([(ref, mov)], dict(num_pyr_lvl=2, tile_size=500),
+                                                dict(num_pyr_lvl=2, tile_size=400, overlap=60, use_full_res_img=True,
+                                                     use_dog=True))
+    assert np.array_equal(final2, final) and np.array_equal(T2, T) and np.array_equal(flow2, flow)
     inner = (slice(120, -120), slice(120, -120))
     err = [np.abs(a[inner].astype(np.float64) - ref[inner]).mean() for a in (mov, affine, final)]
     assert err[1] < 0.5 * err[0] and err[2] < 0.8 * err[1]
