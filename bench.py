@@ -1,17 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: OptFlowRegistrator.register() + one Warper.warp(mov, flow).
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg4|cfg1]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg4|cfg5|cfg1]
 
 A step is one registration + warp of one synthetic (ref, mov) pair that is already resident in HBM.
 Every rank (one process per GPU) works on its own pair -- independent units, no data-path collective
  -- so scaling is weak and `value` = N * H*W / max-over-ranks time.  The control plane
 (barrier, max of the per-rank times) uses torch.distributed/gloo on the host; the GPU is driven only by
 libmicroaligner_hip.so.  Prints ONE JSON line on rank 0.
+
+Launching: under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` every process is a
+rank (RANK / LOCAL_RANK / WORLD_SIZE from the environment).  Started directly with `--gpus N` (N > 1) and no
+WORLD_SIZE in the environment, this process becomes a launcher: it starts N rank processes (the fan-out the
+reference gets from dask, shared_modules/utils.py:117-123) BEFORE anything touches HIP, forwards rank 0's JSON
+line and exits non-zero if any rank fails.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,14 +30,22 @@ METRIC = "Mpix/s optical-flow reg+warp, 16k×16k float32 tile, 1/2/4/8 GPU"  # B
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PK_PEAK_TLOPS = 71.4  # packed FP32 lane-ops/s measured with v_pk_mul_f32 at 8 waves/SIMD (profiles/r01_ubench_valu.txt)
 
+CFG2 = dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=False)
 WORKLOADS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
     "cfg3": dict(shape=(16384, 16384), params=dict(num_pyr_lvl=4, use_full_res_img=True, use_dog=True),
                  desc="16384x16384 f32, DOG preprocess, 5-level pyramid [16,8,4,2,1], tile 1000 / overlap 100 / win 99 / 3 iters"),
-    "cfg2": dict(shape=(4096, 4096), params=dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=False),
+    "cfg2": dict(shape=(4096, 4096), params=CFG2,
                  desc="4096x4096 f32, 3 levels [4,2,1], tile 1000 / overlap 100 / win 99 / 3 iters"),
     "cfg4": dict(shape=(8192, 8192), params=dict(num_pyr_lvl=3, use_full_res_img=True, use_dog=False),
-                 desc="8192x8192 f32 cycle, shipped YAML parameters, one cycle per GPU"),
+                 desc="8192x8192 f32 cycle, shipped YAML parameters (config_1.yaml:42-49), one cycle pair per GPU "
+                      "(independent pairs against a fixed reference; the reference's chain is serial)"),
+    # BASELINE.json configs[4]: one mosaic tile per step; the affine initialisation is the known synthetic matrix
+    # applied with the dense warp kernel (ground-truth matrix where opencv-contrib is absent), then
+    # the optical-flow refinement as cfg2
+    "cfg5": dict(shape=(4096, 4096), params=CFG2, affine=True,
+                 desc="4096x4096 f32 mosaic tile: affine init (known synthetic similarity, warp_affine kernel) then "
+                      "optical-flow refinement as cfg2 + warp; tiles dealt round-robin to the GPUs"),
     "cfg1": dict(shape=(512, 512), params=dict(), desc="512x512 f32, class defaults (plumbing)"),
 }
 
@@ -58,17 +74,19 @@ def algorithmic_bytes_per_px(kernel, iters, esz):
 
 
 def pmc_traffic(workload):
-    """HBM bytes per step and kernel group from the committed rocprofv3 PMC summary of this very command
+    """HBM bytes per step and kernel group from the newest committed rocprofv3 PMC summary of this very command
     (profiles/rNN_hbm_traffic_<workload>.json, tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE
-    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the bench."""
+    passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the bench,
+    so the JSON line names the file the bytes come from (`traffic_source`); it is regenerated whenever a kernel's
+    I/O changes."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_{workload}.json")))
     if not files:
-        return {}
-    return json.load(open(files[-1])).get("per_bench_group_bytes_per_step", {})
+        return {}, None
+    return json.load(open(files[-1])).get("per_bench_group_bytes_per_step", {}), os.path.relpath(files[-1], ROOT)
 
 
-def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsize_taps=0):
+def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsize_taps=0, traffic_source=None):
     if rec["launches"] == 0 or rec["ms"] <= 0:
         return None
     bpp = algorithmic_bytes_per_px(name, iters, esz)
@@ -78,6 +96,7 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
         traffic = round(traffic_per_step[name] * steps / rec["launches"])  # HBM bytes per launch (PMC)
     out = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+           "traffic_source": traffic_source if traffic is not None else None,
            "avg_launch_ms": round(rec["ms"] / rec["launches"], 4), "launches": rec["launches"],
            "algorithmic_bytes_per_launch": round(bpp * rec["px"] / rec["launches"]),
            "algorithmic_bytes_per_px": round(bpp, 2), "px_per_launch": round(rec["px"] / rec["launches"])}
@@ -92,25 +111,41 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
     return out
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sample, params):
-    """The CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload, host cores of this box."""
-    import numpy as np  # noqa: F401
+    """The CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload on every host core of this
+    box: Farneback windows, image rows (DOG, pyramids, remap) and NMI chunks fan out over OpenMP threads, one per
+    hardware thread -- the analogue of the reference's dask scheduler="processes" fan-out (utils.py:117-119,
+    flow_calc.py:93-97, similarity_scoring.py:44-48).  No cv2 on the box, so this is the restatement, not OpenCV."""
     from microaligner_amd import synthetic
     from oracle import register_oracle as RO
-    # only the Farneback windows of a level fan out over threads (OpenMP, one window per thread); the largest level
-    # of the sample has nwin windows, so that is the number of host threads actually busy
-    nwin = (-(-sample // params.get("tile_size", 1000))) ** 2
-    cores = min(os.cpu_count() or 1, nwin)
+    cores = os.cpu_count() or 1
     ref, mov = synthetic.make_pair(sample, sample, 1)
+    stages = {}
     t0 = time.perf_counter()
-    flow, _ = RO.register(ref, mov, nthreads=cores, **params)
+    flow, _ = RO.register(ref, mov, nthreads=cores, stage_seconds=stages, **params)
+    tw = time.perf_counter()
     RO.warp(mov, flow, params.get("tile_size", 1000), params.get("overlap", 100))
-    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    stages["final_warp"] = t1 - tw
+    dt = t1 - t0
+    nwin = (-(-sample // params.get("tile_size", 1000))) ** 2
     return {"value": round(sample * sample / dt / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
-            "sample": f"{sample}x{sample} f32 pair, same parameters as the GPU workload, register()+warp(); the "
-                      f"{nwin} Farneback windows of the largest level run on {cores} OpenMP threads (one window per "
-                      f"thread, as the reference's dask fan-out; host has {os.cpu_count()} hardware threads), every other "
-                      f"stage is single-threaded; {dt:.1f} s of wall time"}
+            "cpu": cpu_model(), "stage_seconds": {k: round(v, 2) for k, v in stages.items()},
+            "sample": f"{sample}x{sample} f32 pair, same parameters as the GPU workload, register()+warp(), "
+                      f"{dt:.1f} s wall; C restatement of the OpenCV / scikit-learn arithmetic (no cv2 in the image) "
+                      f"with {cores} OpenMP threads: the Farneback windows of a level ({nwin} at full resolution, one "
+                      f"window per thread), image rows of DOG / pyramid / remap and NMI chunks run in parallel; "
+                      f"tile cutting / stitching is single-threaded numpy as in the reference"}
 
 
 def lanes_leg(lanes, steps, device, dref, dmov, params, tile, overlap):
@@ -118,42 +153,121 @@ def lanes_leg(lanes, steps, device, dref, dmov, params, tile, overlap):
     import threading
     from microaligner_amd import OptFlowRegistrator, Warper
     from microaligner_amd.device import Context, use_context
-    bar, spans = threading.Barrier(lanes), []
+    bar, spans, errors = threading.Barrier(lanes), [], []
 
     def lane():
-        ctx = Context(device)
-        with use_context(ctx):
-            reg = OptFlowRegistrator()
-            reg.verbose = False
-            for k, v in params.items():
-                setattr(reg, k, v)
-            w = Warper()
-            w.tile_size, w.overlap = tile, overlap
+        ctx = None
+        try:
+            ctx = Context(device)
+            with use_context(ctx):
+                reg = OptFlowRegistrator()
+                reg.verbose = False
+                for k, v in params.items():
+                    setattr(reg, k, v)
+                w = Warper()
+                w.tile_size, w.overlap = tile, overlap
 
-            def one():
-                reg.ref_img, reg.mov_img = dref, dmov   # read-only inputs shared by the lanes
-                flow = reg.register()
-                w.image, w.flow = dmov, flow
-                return w.warp()
+                def one():
+                    reg.ref_img, reg.mov_img = dref, dmov   # read-only inputs shared by the lanes
+                    flow = reg.register()
+                    w.image, w.flow = dmov, flow
+                    return w.warp()
 
-            one()
-            ctx.sync()
-            bar.wait()
-            t0 = time.perf_counter()
-            for _ in range(steps):
                 one()
-            ctx.sync()
-            spans.append((t0, time.perf_counter()))
-        ctx.close()
+                ctx.sync()
+                bar.wait(timeout=600)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    one()
+                ctx.sync()
+                spans.append((t0, time.perf_counter()))
+        except BaseException as e:  # a failed lane must not leave the others waiting at the barrier
+            errors.append(e)
+            bar.abort()
+        finally:
+            if ctx is not None:
+                ctx.close()
 
     th = [threading.Thread(target=lane) for _ in range(lanes)]
     for t in th:
         t.start()
     for t in th:
         t.join()
-    if len(spans) != lanes:
-        raise RuntimeError("a lane failed")
+    if errors or len(spans) != lanes:
+        first = next((e for e in errors if not isinstance(e, threading.BrokenBarrierError)), errors[0] if errors else None)
+        raise RuntimeError(f"a lane failed: {first!r}")
     return (max(b for _, b in spans) - min(a for a, _ in spans)) / (lanes * steps)
+
+
+def host_inclusive_leg(steps, ref, mov, params):
+    """numpy in -> numpy out through the drop-in API (optflow_registrator.py:93,173; warper.py:53): H2D of both
+    images, register(), warp(), D2H of the flow and the warped image, per pair."""
+    from microaligner_amd import OptFlowRegistrator, Warper
+    reg = OptFlowRegistrator()
+    reg.verbose = False
+    for k, v in params.items():
+        setattr(reg, k, v)
+    w = Warper()
+    w.tile_size, w.overlap = reg.tile_size, reg.overlap
+
+    def one():
+        reg.ref_img, reg.mov_img = ref, mov
+        flow = reg.register()
+        w.image, w.flow = mov, flow
+        return flow, w.warp()
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        flow, warped = one()
+    dt = (time.perf_counter() - t0) / steps
+    assert flow.shape == ref.shape + (2,) and warped.shape == ref.shape
+    return dt
+
+
+# ---- launcher ----------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """Start n rank processes of this script and forward rank 0's stdout.  Nothing in this process has touched HIP
+    (no microaligner_amd import, no torch.cuda call) -- the ranks are plain children, never an exec of a process
+    that initialised the GPU."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with status {code}; stopping the other ranks", file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()   # exact children of this process, by handle
+        if pending:
+            time.sleep(0.05)
+    out = procs[0].stdout.read().decode()
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if rc == 0 and not any(line.startswith("{") for line in out.splitlines()):
+        print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
 
 
 def main():
@@ -163,37 +277,84 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--size", type=int, default=0, help="override H=W of the workload")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "u8"], help="input dtype (u8: the pipeline-faithful cfg4 variant)")
     ap.add_argument("--fused", action="store_true", help="window blur with FMA (MA_FB_MULADD_FUSED)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dog", action="store_true", help="experiment: run the workload with use_dog=False")
-    ap.add_argument("--no-variants", action="store_true", help="skip the informational FMA-mode leg (profiling runs)")
-    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--no-variants", action="store_true", help="skip the informational legs (profiling runs)")
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--lanes", type=int, default=3, help="pairs in flight for the informational multi-lane leg (0: skip)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / reduce plumbing only, no GPU work (CPU test of the N-rank launcher)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    import numpy as np
-    from microaligner_amd import OptFlowRegistrator, Warper, synthetic
-    from microaligner_amd.device import get_context
-
     wl = WORKLOADS[args.workload]
     H, W = (args.size, args.size) if args.size else wl["shape"]
     params = dict(wl["params"])
     if args.no_dog:
         params["use_dog"] = False
-    ctx = get_context(local_rank)
 
-    ref, mov = synthetic.make_pair(H, W, seed=1 + rank)
+    def reduce_max(x):
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.dry_run:
+        if dist is not None:
+            dist.barrier()
+        elapsed = reduce_max(1e-3 * args.steps)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "dry_run": True,
+                              "config": {"workload": args.workload, "pairs_per_step": world}}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    import numpy as np
+    from microaligner_amd import OptFlowRegistrator, Warper, synthetic
+    from microaligner_amd.device import device_count, get_context
+
+    ndev = device_count()
+    if ndev < 1:
+        raise RuntimeError("no HIP device: the benchmark has no CPU path")
+    # one process per GPU; on a box with fewer GPUs than ranks (the 1-GPU test box) ranks share devices, which the
+    # JSON line states (`devices`)
+    ctx = get_context(local_rank % ndev)
+
+    np_dtype = np.uint8 if args.dtype == "u8" else np.float32
+    ref, mov = synthetic.make_pair(H, W, seed=1 + rank, dtype=np_dtype)
+    inv_affine = None
+    if wl.get("affine"):
+        # mosaic tile: the moving image additionally carries a known similarity (rotation <= 0.5 deg, shift <= 20 px)
+        rng = np.random.default_rng(100 + rank)
+        ang = np.deg2rad(rng.uniform(-0.5, 0.5))
+        tx, ty = rng.uniform(-20, 20, 2)
+        c, s = np.cos(ang), np.sin(ang)
+        fwd = np.array([[c, -s, tx + (1 - c) * W / 2 + s * H / 2], [s, c, ty - s * W / 2 + (1 - c) * H / 2], [0, 0, 1]])
+        mov = ctx.warp_affine(ctx.asdevice(mov), fwd).numpy()          # misplace the tile ...
+        inv_affine = np.linalg.inv(fwd)                                # ... the initialisation undoes it
     dref, dmov = ctx.asdevice(ref), ctx.asdevice(mov)
-    del ref, mov
+    if not (world == 1 and not args.no_variants):
+        del ref, mov
 
     reg = OptFlowRegistrator()
     reg.verbose = False
@@ -204,9 +365,10 @@ def main():
     warper.tile_size, warper.overlap = reg.tile_size, reg.overlap
 
     def step():
-        reg.ref_img, reg.mov_img = dref, dmov
+        m = dmov if inv_affine is None else ctx.warp_affine(dmov, inv_affine)   # transform_img_with_tmat (utils.py:98-114)
+        reg.ref_img, reg.mov_img = dref, m
         flow = reg.register()
-        warper.image, warper.flow = dmov, flow
+        warper.image, warper.flow = m, flow
         return warper.warp()
 
     def barrier():
@@ -226,22 +388,18 @@ def main():
     t1 = time.perf_counter()
     barrier()
     ctx.profile(False)
-    elapsed = t1 - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_max(t1 - t0)
     del out
 
     if rank == 0:
         prof = ctx.profile_get()
-        iters, esz = reg.num_iterations, 4
-        # with use_dog the Farneback inputs are the uint8 DOG images (1 B/px), not the f32 level images
+        iters, esz = reg.num_iterations, np.dtype(np_dtype).itemsize
+        # with use_dog the Farneback inputs are the uint8 DOG images (1 B/px), not the level images
         fb_esz = 1 if reg.use_dog else esz
-        tps = pmc_traffic(args.workload) if not args.size and not args.fused and not args.no_dog else {}
+        pristine = not args.size and not args.fused and not args.no_dog and args.dtype == "f32"
+        tps, tsrc = pmc_traffic(args.workload) if pristine else ({}, None)
         win = reg.overlap - (1 - reg.overlap % 2)
-        kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz, args.steps, tps, win // 2)
+        kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz, args.steps, tps, win // 2, tsrc)
                    for k, v in prof.items()}
         kernels = {k: v for k, v in kernels.items() if v}
         total_kernel_ms = sum(v["ms"] for v in prof.values())
@@ -252,18 +410,28 @@ def main():
             "metric": METRIC, "value": round(world * H * W * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}" + (f" (size overridden to {H})" if args.size else ""),
                        "pairs_per_step": world, "tile_size": reg.tile_size, "overlap": reg.overlap,
                        "num_iterations": reg.num_iterations, "muladd": "fma" if args.fused else "mul+add",
                        "levels": [[r.factor, r.accepted] for r in reg.level_reports],
-                       "parallelism": f"{world} independent pairs, one per GPU, no collective"},
+                       "devices": ndev,
+                       "parallelism": f"{world} independent pairs, one rank per pair, {min(world, ndev)} GPU(s), no collective"},
             "roofline": kernels.get(dominant),
             "roofline_polyexp": kernels.get("polyexp_m0"),
             "kernels": kernels,
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 3),
         }
         if world == 1 and not args.fused and not args.no_variants:
+            res["variants"] = {}
+            # informational: the drop-in API as the reference's callers use it, numpy in -> numpy out (PCIe inclusive;
+            # never the headline value)
+            th = host_inclusive_leg(max(1, min(args.steps, 3)), ref, mov if inv_affine is None else
+                                    ctx.warp_affine(dmov, inv_affine).numpy(), params)
+            res["variants"]["host_inclusive"] = {"value": round(H * W / th / 1e6, 2), "unit": "Mpix/s",
+                                                 "ms_per_step": round(th * 1e3, 3),
+                                                 "what": "numpy in -> numpy out: H2D of ref and mov, register(), warp(), D2H of flow and warped image"}
+            del ref, mov
             # informational: the same workload with the window blur in the FMA rounding model
             # (MA_FB_MULADD_FUSED: OpenCV builds whose v_muladd is a fused multiply-add); not the headline value
             reg.muladd_fused = True
@@ -275,9 +443,9 @@ def main():
             ctx.sync()
             tf = (time.perf_counter() - tf0) / args.steps
             reg.muladd_fused = False
-            res["variants"] = {"muladd_fma": {"value": round(H * W / tf / 1e6, 2), "unit": "Mpix/s",
-                                              "ms_per_step": round(tf * 1e3, 3)}}
-            if args.lanes > 1:
+            res["variants"]["muladd_fma"] = {"value": round(H * W / tf / 1e6, 2), "unit": "Mpix/s",
+                                             "ms_per_step": round(tf * 1e3, 3)}
+            if args.lanes > 1 and inv_affine is None:
                 # informational: `lanes` independent pairs in flight on this GPU, one context (HIP stream, workspace)
                 # and one host thread per lane -- what parallel.register_pairs(lanes=...) does for a list of pairs
                 tl = lanes_leg(args.lanes, args.steps, ctx.device, dref, dmov, params, reg.tile_size, reg.overlap)
@@ -285,7 +453,7 @@ def main():
                     "value": round(H * W / tl / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(tl * 1e3, 3),
                     "pairs_in_flight": args.lanes}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_sample, params)
+            res["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, H), params)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -71,6 +71,14 @@ int ma_free(ma_ctx* ctx, void* dptr);
 int ma_memcpy_h2d(ma_ctx* ctx, void* dst, const void* src_host, size_t bytes);
 int ma_memcpy_d2h(ma_ctx* ctx, void* dst_host, const void* src, size_t bytes); /* synchronises */
 int ma_memcpy_d2d(ma_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* Result transfer of the numpy-in / numpy-out API (register() returns the flow, optflow_registrator.py:173;
+ * Warper.warp() returns the image, warper.py:53): enqueue only, the caller waits with ma_sync.  dst_host should
+ * be page-locked (ma_host_alloc) for the copy to overlap later kernels; pageable memory makes HIP stage it. */
+int ma_memcpy_d2h_async(ma_ctx* ctx, void* dst_host, const void* src, size_t bytes);
+/* Page-locked host memory, portable across devices, for result arrays that are reused from call to call (a fresh
+ * pageable array costs a first-touch page fault per 4 KiB on every call).  Not tied to a ctx. */
+int ma_host_alloc(size_t bytes, void** hptr);
+int ma_host_free(void* hptr);
 int ma_memset(ma_ctx* ctx, void* dst, int value, size_t bytes);
 
 /* ---- timing (HIP events on the ctx stream) ------------------------------ */

@@ -73,6 +73,37 @@ __device__ __forceinline__ void window_extent(const FbGeom& g, int oy, int ox, i
     ex = min(g.t.Pw, vx + min(g.margin, g.t.Pw));
 }
 
+// Needed extent of a window (the mirror image of the active extent: that one drops what cannot be non-zero, this
+// one drops what nobody reads).  Of a tiled window only the centre crop [ov, ov+T) (clipped to the image) reaches
+// the stitched flow (stitcher.py:62-65).  Walking the data flow backwards -- crop <- horizontal pass <- vertical
+// pass <- UpdateMatrices (pointwise in the flow) <- previous iteration -- the horizontal pass of the iteration
+// that has `rem` iterations after it is needed on  crop +- rem*m, its vertical pass on the same rows and m more
+// columns either side, and the M it writes exactly where the next vertical pass reads.  Blocks outside exit;
+// values outside the rectangle are stale but only ever feed outputs that are outside the next rectangle.
+// Bit-identical to blurring the whole window; 13 % less blur work at 3 iterations, tile 1000, overlap 100.
+struct FbRect { int y0, y1, x0, x1; };
+__host__ __device__ __forceinline__ FbRect needed_rect_h(const MaTiling& t, int oy, int ox, int reach)
+{
+    FbRect r;
+    if (t.T == 0) { r.y0 = 0; r.y1 = t.Ph; r.x0 = 0; r.x1 = t.Pw; return r; }
+    const int cy1 = t.ov + t.T < t.H - oy ? t.ov + t.T : t.H - oy;
+    const int cx1 = t.ov + t.T < t.W - ox ? t.ov + t.T : t.W - ox;
+    r.y0 = t.ov - reach > 0 ? t.ov - reach : 0;
+    r.x0 = t.ov - reach > 0 ? t.ov - reach : 0;
+    r.y1 = cy1 + reach < t.Ph ? cy1 + reach : t.Ph;
+    r.x1 = cx1 + reach < t.Pw ? cx1 + reach : t.Pw;
+    return r;
+}
+__host__ __device__ __forceinline__ FbRect needed_rect_v(const MaTiling& t, int oy, int ox, int reach, int m)
+{
+    FbRect r = needed_rect_h(t, oy, ox, reach);
+    r.x0 = r.x0 - m > 0 ? r.x0 - m : 0;
+    r.x1 = r.x1 + m < t.Pw ? r.x1 + m : t.Pw;
+    return r;
+}
+// block grids start at the rectangle's corner, columns aligned down to 128 bytes for the row accesses
+constexpr int NEED_XALIGN = 32;
+
 // ---------------------------------------------------------------------------------------------
 // K1: pre-blur + polynomial expansion of both images + first UpdateMatrices (flow == 0)
 // ---------------------------------------------------------------------------------------------
@@ -274,7 +305,7 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
 constexpr int BV_WAVES = 6, BH_WAVES = 6;
 template <int R, int NW, bool FUSED>
 __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v(FbGeom g, int m, const float* __restrict__ taps,
-                                                     float* __restrict__ ws, int nplanes)
+                                                     float* __restrict__ ws, int nplanes, int reach)
 {
     extern __shared__ float lds[];  // [(NW*R + 2m)][64]
     const int lane = threadIdx.x & 63;
@@ -291,14 +322,15 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v(FbGeom g, int m, 
     const int by = item % nby, bx = (item / nby) % nbx;
     const int bz = d_xcd_unit(item / (nby * nbx), nplanes);
     if (bz >= nplanes) return;
-    const int x0 = bx * 64, y0 = by * (NW * R);
     const int wl = bz / 5, ch = bz - wl * 5;
     const float* src = plane_ptr(ws, g, wl, PL_M + ch);
     float* dst = plane_ptr(ws, g, wl, PL_V + ch);
     int oy, ox, ey, ex;
     window_origin(g.t, g.tile0 + wl, oy, ox);
     window_extent(g, oy, ox, ey, ex);
-    if (x0 >= ex || y0 >= ey) return;
+    const FbRect need = needed_rect_v(g.t, oy, ox, reach, m);
+    const int x0 = (need.x0 & ~(NEED_XALIGN - 1)) + bx * 64, y0 = need.y0 + by * (NW * R);
+    if (x0 >= min(ex, need.x1) || y0 >= min(ey, need.y1)) return;
 
     constexpr int G = 2;  // guard rows on either side (d_sym_fir_slide contract)
     const int rows = NW * R + 2 * m + 2 * G;
@@ -326,15 +358,16 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v(FbGeom g, int m, 
     }
     __syncthreads();
 
+    if (y0 + w * R >= min(ey, need.y1)) return;  // this wave's rows are not needed (no barrier follows)
     float acc[R];
     d_sym_fir_slide_pk<R, FUSED, true>(lds + lane, G + m + w * R, m, taps, acc);
     const int x = x0 + lane;
     const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(g.plane * sizeof(float)), 0x00020000);
-    if (x < Pw) {
+    if (x >= need.x0 && x < need.x1) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int y = y0 + w * R + r;
-            if (y < Ph) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), drsrc, x * 4, y * g.pitch * 4, 0);
+            if (y < need.y1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), drsrc, x * 4, y * g.pitch * 4, 0);
         }
     }
 }
@@ -349,7 +382,7 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v(FbGeom g, int m, 
 template <int R, int NW, bool FUSED, int Q>
 __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, int m, const float* __restrict__ taps,
                                                            float* __restrict__ ws, int last,
-                                                           float* __restrict__ flow_out, int nwin)
+                                                           float* __restrict__ flow_out, int nwin, int reach)
 {
     extern __shared__ float lds[];
     constexpr int TXW = NW * R;           // output columns per block
@@ -363,13 +396,14 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
     const int nslots = (int)(((nwin + 7) / 8) * 8);
     const int item = d_xcd_work_item(blockIdx.x, nbx * nby * nslots);
     const int bx = item % nbx, by = (item / nbx) % nby;
-    const int x0 = bx * TXW, y0 = by * 64;
     const int wl = d_xcd_unit(item / (nbx * nby), nwin);  // windows interleaved over the XCDs (see fb_blur_v)
     if (wl >= nwin) return;
     int oy, ox, ey, ex;
     window_origin(g.t, g.tile0 + wl, oy, ox);
     window_extent(g, oy, ox, ey, ex);
-    if (x0 >= ex || y0 >= ey) return;
+    const FbRect need = needed_rect_h(g.t, oy, ox, reach);
+    const int x0 = (need.x0 & ~(NEED_XALIGN - 1)) + bx * TXW, y0 = need.y0 + by * 64;
+    if (x0 >= min(ex, need.x1) || y0 >= min(ey, need.y1)) return;
     constexpr int G = 2;  // guard columns on either side (d_sym_fir_slide contract)
     const int cols = TXW + 2 * m + 2 * G;
     const int lp = cols | 1;              // odd LDS pitch: lanes (rows) hit distinct banks
@@ -411,13 +445,19 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
     };
 
     float hs[5][R];
+    const bool wave_needed = x0 + w * R < min(ex, need.x1);  // else: this wave's columns feed nothing (it still stages)
     issue(0);
 #pragma unroll
     for (int ch = 0; ch < 5; ch++) {
         commit();
         __syncthreads();
         float acc[R];
-        d_sym_fir_slide_pk<R, FUSED, false>(lds + lane * lp, G + m + w * R, m, taps, acc);
+        if (wave_needed) {
+            d_sym_fir_slide_pk<R, FUSED, false>(lds + lane * lp, G + m + w * R, m, taps, acc);
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) hs[ch][r] = acc[r];
         __syncthreads();
@@ -437,7 +477,7 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
         for (int p = tid; p < 32 * TXW; p += NT) {
             const int rh = p / TXW, c = p - rh * TXW;
             const int y = y0 + half * 32 + rh, x = x0 + c;
-            if (y < Ph && x < Pw) {
+            if (y < need.y1 && x >= need.x0 && x < need.x1) {
                 double g11 = lds[(0 * 32 + rh) * TP + c], g12 = lds[(1 * 32 + rh) * TP + c],
                        g22 = lds[(2 * 32 + rh) * TP + c], h1 = lds[(3 * 32 + rh) * TP + c],
                        h2 = lds[(4 * 32 + rh) * TP + c];
@@ -675,13 +715,22 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
     const bool fast = m >= 1 && lds_v <= LDS_MAX && lds_h <= LDS_MAX && colsh <= 320;  // 320 = 5 chunks (winsize <= 253)
     // the LDS-staged kernels honour the active extent; the fallback kernels process whole windows
     g.margin = fast ? (iters - 1) * m + 3 : (1 << 28);
-    // pixels actually processed (inside the active extents) -- the unit of the per-kernel accounting
+    // pixels actually processed -- the unit of the per-kernel accounting: the active extent for the expansion
+    // kernel, active extent x needed rectangle for the two passes of every iteration
     double px = 0;
+    std::vector<double> px_v(iters, 0.0), px_h(iters, 0.0);
     for (int wl = 0; wl < nwin; wl++) {
         int oy = 0, ox = 0;
         if (g.t.T > 0) { int ty = (g.tile0 + wl) / g.t.ntx, tx = (g.tile0 + wl) % g.t.ntx; oy = ty * g.t.T - g.t.ov; ox = tx * g.t.T - g.t.ov; }
         const int vy = std::min(Ph, g.t.H - oy), vx = std::min(Pw, g.t.W - ox);
-        px += (double)std::min(Ph, vy + std::min(g.margin, Ph)) * std::min(Pw, vx + std::min(g.margin, Pw));
+        const int ey = std::min(Ph, vy + std::min(g.margin, Ph)), ex = std::min(Pw, vx + std::min(g.margin, Pw));
+        px += (double)ey * ex;
+        for (int it = 0; it < iters; it++) {
+            const int reach = fast ? (iters - 1 - it) * m : (1 << 28) / 2;
+            const FbRect rh = needed_rect_h(g.t, oy, ox, reach), rv = needed_rect_v(g.t, oy, ox, reach, m);
+            px_h[it] += (double)std::max(0, std::min(ey, rh.y1) - rh.y0) * std::max(0, std::min(ex, rh.x1) - rh.x0);
+            px_v[it] += (double)std::max(0, std::min(ey, rv.y1) - rv.y0) * std::max(0, std::min(ex, rv.x1) - rv.x0);
+        }
     }
     {
         MaProfScope ps(ctx, MA_K_POLYEXP_M0, px);
@@ -690,22 +739,23 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
     }
     for (int it = 0; it < iters; it++) {
         const int last = it == iters - 1;
+        const int reach = (iters - 1 - it) * m;  // see needed_rect_h
         if (fast) {
             {
-                MaProfScope ps(ctx, MA_K_BLUR_V, px);
+                MaProfScope ps(ctx, MA_K_BLUR_V, px_v[it]);
                 const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * ma_xcd_slots(nwin * 5);
                 hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_v,
-                                   ctx->stream, g, m, taps, ws, nwin * 5);
+                                   ctx->stream, g, m, taps, ws, nwin * 5, reach);
             }
             {
-                MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px);
+                MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px_h[it]);
                 const long long items = (long long)((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R)) * ((Ph + 63) / 64) * ma_xcd_slots(nwin);
                 if (colsh <= 192)
                     hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 3>), dim3(ma_xcd_grid(items)),
-                                       dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin);
+                                       dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin, reach);
                 else
                     hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 5>), dim3(ma_xcd_grid(items)),
-                                       dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin);
+                                       dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin, reach);
             }
         } else {
             {

@@ -134,6 +134,33 @@ int ma_memcpy_d2h(ma_ctx* ctx, void* dst_host, const void* src, size_t bytes)
     return MA_OK;
 }
 
+int ma_memcpy_d2h_async(ma_ctx* ctx, void* dst_host, const void* src, size_t bytes)
+{
+    MA_REQUIRE(ctx && (bytes == 0 || (dst_host && src)), "NULL argument");
+    if (!bytes) return MA_OK;
+    MA_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return MA_OK;
+}
+
+int ma_host_alloc(size_t bytes, void** hptr)
+{
+    MA_REQUIRE(hptr != nullptr, "hptr is NULL");
+    *hptr = nullptr;
+    if (bytes == 0) bytes = 1;
+    hipError_t e = hipHostMalloc(hptr, bytes, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        ma_set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? MA_ENOMEM : MA_EHIP;
+    }
+    return MA_OK;
+}
+
+int ma_host_free(void* hptr)
+{
+    if (hptr) MA_HIP(hipHostFree(hptr));
+    return MA_OK;
+}
+
 int ma_memcpy_d2d(ma_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     MA_REQUIRE(ctx && (bytes == 0 || (dst && src)), "NULL argument");

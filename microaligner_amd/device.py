@@ -49,11 +49,24 @@ class DeviceArray:
     def __len__(self):
         return self.shape[0] if self.shape else 0
 
-    def numpy(self):
-        out = np.empty(self.shape, self.dtype)
+    def numpy(self, out=None):
+        """Copy to the host.  Without `out` the result array comes from the context's pool of page-locked,
+        already-faulted host buffers (Context.host_empty): an ordinary ndarray whose memory goes back to the pool
+        when the last reference to it (or to a view of it) is dropped.  `out`: a C-contiguous array of the same
+        shape and dtype to fill instead (e.g. a row of the caller's memmap)."""
+        self._check_alive()
+        if out is None:
+            out = self.ctx.host_empty(self.shape, self.dtype)
+        elif (tuple(out.shape) != self.shape or out.dtype != self.dtype or not out.flags.c_contiguous
+              or not out.flags.writeable):
+            raise ValueError(f"out must be a writable C-contiguous {self.dtype} array of shape {self.shape}")
         if out.nbytes:
             L.check(self.ctx.lib.ma_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
         return out
+
+    def _check_alive(self):
+        if self.ptr is None or self.ctx is None or self.ctx._closed:
+            raise RuntimeError("this DeviceArray was freed (its context is closed or free() was called)")
 
     def copy(self):
         out = self.ctx.empty(self.shape, self.dtype)
@@ -72,6 +85,26 @@ class DeviceArray:
             pass
 
 
+class _HostBuffer:
+    """Owner of one page-locked host buffer; exposes it through __array_interface__ so that numpy arrays built on
+    it keep it alive (base chain), and hands the memory back to the pool when it dies."""
+
+    __slots__ = ("ctx", "ptr", "bucket", "nbytes")
+
+    def __init__(self, ctx, ptr, bucket, nbytes):
+        self.ctx, self.ptr, self.bucket, self.nbytes = ctx, ptr, bucket, nbytes
+
+    @property
+    def __array_interface__(self):        # numpy (any Python): zero-copy view, base object = self
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        try:
+            self.ctx._host_release(self.ptr, self.bucket)
+        except Exception:
+            pass
+
+
 class Context:
     """One per HIP device.  Owns the C-side ma_ctx and a size-bucketed pool of HBM buffers."""
 
@@ -82,6 +115,9 @@ class Context:
         self.handle = h
         self.device = int(device)
         self._pool = {}
+        self._live = {}        # ptr -> bucket of every buffer handed out and not yet released
+        self._host_pool = {}   # bucket -> [pinned host pointers] (result arrays of the numpy-in / numpy-out API)
+        self._host_lock = threading.Lock()
         self._closed = False
         lim = os.environ.get("MICROALIGNER_WORKSPACE_GB")
         if lim:
@@ -104,6 +140,7 @@ class Context:
                 rc = self.lib.ma_malloc(self.handle, bucket, C.byref(p))
             L.check(rc)
             ptr = p.value
+        self._live[ptr] = bucket
         return DeviceArray(self, shape, dtype, ptr, bucket)
 
     def zeros(self, shape, dtype):
@@ -124,22 +161,76 @@ class Context:
 
     def _release(self, ptr, bucket):
         if self._closed:
-            return
+            return   # close() already returned every outstanding buffer to the driver
+        self._live.pop(ptr, None)
         self._pool.setdefault(bucket, []).append(ptr)
 
     def trim(self):
-        """Return every pooled buffer to the driver."""
+        """Return every pooled buffer (device and host) to the driver."""
         for free in self._pool.values():
             for p in free:
                 self.lib.ma_free(self.handle, p)
         self._pool = {}
+        with self._host_lock:
+            pools, self._host_pool = self._host_pool, {}
+        for free in pools.values():
+            for p in free:
+                self.lib.ma_host_free(p)
+
+    def _run(self, fn, *args):
+        """Call a compute entry point; on MA_ENOMEM hand the cached buffers back to the driver and retry once
+        (the pool never shrinks by itself and can hold tens of GB of flow-sized buffers)."""
+        rc = fn(self.handle, *args)
+        if rc == L.MA_ENOMEM:
+            self.trim()
+            rc = fn(self.handle, *args)
+        L.check(rc)
+
+    # page-locked result arrays ---------------------------------------------------------------
+    HOST_POOL_PER_BUCKET = 3
+
+    def host_empty(self, shape, dtype):
+        """ndarray on page-locked host memory drawn from a pool.  The memory returns to the pool when the array
+        and all views of it are gone (the array's base object is the owner), so a loop that keeps calling
+        register() / warp() reuses the same already-faulted, DMA-able buffers instead of paying a page fault per
+        4 KiB of every fresh result."""
+        shape = tuple(int(s) for s in shape)
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes < (1 << 20):          # small results: not worth a pinned allocation
+            return np.empty(shape, dtype)
+        bucket = (nbytes + 0x1FFFFF) & ~0x1FFFFF
+        with self._host_lock:
+            free = self._host_pool.get(bucket)
+            ptr = free.pop() if free else None
+        if ptr is None:
+            p = C.c_void_p()
+            rc = self.lib.ma_host_alloc(bucket, C.byref(p))
+            if rc != L.MA_OK:           # page-locked memory exhausted: fall back to a pageable array
+                return np.empty(shape, dtype)
+            ptr = p.value
+        owner = _HostBuffer(self, ptr, bucket, nbytes)
+        return np.asarray(owner).view(dtype).reshape(shape)   # base chain ends at `owner`
+
+    def _host_release(self, ptr, bucket):
+        with self._host_lock:
+            free = self._host_pool.setdefault(bucket, [])
+            if not self._closed and len(free) < self.HOST_POOL_PER_BUCKET:
+                free.append(ptr)
+                return
+        self.lib.ma_host_free(ptr)
 
     def sync(self):
         L.check(self.lib.ma_sync(self.handle))
 
     def close(self):
         if not self._closed:
+            L.check(self.lib.ma_sync(self.handle))
             self.trim()
+            # arrays that outlive the context: their HBM goes back to the driver now (they raise if used again)
+            for p in list(self._live):
+                self.lib.ma_free(self.handle, p)
+            self._live = {}
             self._closed = True
             self.lib.ma_ctx_destroy(self.handle)
 
@@ -185,18 +276,18 @@ class Context:
             raise ValueError("prev/next must be 2-D arrays of the same shape and dtype")
         H, W = prev.shape
         flow = self.empty((H, W, 2), np.float32)
-        L.check(self.lib.ma_farneback_tiled(self.handle, prev.ptr, nxt.ptr, _dt(prev.dtype), H, W, int(tile),
+        self._run(self.lib.ma_farneback_tiled, prev.ptr, nxt.ptr, _dt(prev.dtype), H, W, int(tile),
                                             int(overlap), int(winsize), int(iterations), int(poly_n),
-                                            float(poly_sigma), L.MA_FB_MULADD_FUSED if fused else 0, flow.ptr))
+                                            float(poly_sigma), L.MA_FB_MULADD_FUSED if fused else 0, flow.ptr)
         return flow
 
     def farneback_debug(self, prev, nxt, winsize, iterations, poly_sigma=1.7, fused=False):
         H, W = prev.shape
         flow = self.empty((H, W, 2), np.float32)
         r0, r1, m0 = (self.empty((5, H, W), np.float32) for _ in range(3))
-        L.check(self.lib.ma_farneback_debug(self.handle, prev.ptr, nxt.ptr, _dt(prev.dtype), H, W, int(winsize),
+        self._run(self.lib.ma_farneback_debug, prev.ptr, nxt.ptr, _dt(prev.dtype), H, W, int(winsize),
                                             int(iterations), float(poly_sigma),
-                                            L.MA_FB_MULADD_FUSED if fused else 0, flow.ptr, r0.ptr, r1.ptr, m0.ptr))
+                                            L.MA_FB_MULADD_FUSED if fused else 0, flow.ptr, r0.ptr, r1.ptr, m0.ptr)
         return flow, r0, r1, m0
 
     def remap(self, src, map_xy):
@@ -207,8 +298,8 @@ class Context:
         if map_xy.dtype != np.float32 or map_xy.ndim != 3 or map_xy.shape[2] != 2:
             raise ValueError("map must be (h, w, 2) float32")
         dst = self.empty((dh, dw) if src.ndim == 2 else (dh, dw, cn), src.dtype)
-        L.check(self.lib.ma_remap_bilinear(self.handle, src.ptr, _dt(src.dtype), cn, sh, sw, map_xy.ptr, dh, dw,
-                                           dst.ptr))
+        self._run(self.lib.ma_remap_bilinear, src.ptr, _dt(src.dtype), cn, sh, sw, map_xy.ptr, dh, dw,
+                                           dst.ptr)
         return dst
 
     def warp(self, img, flow, tile, overlap, minmax=False):
@@ -220,11 +311,11 @@ class Context:
         out = self.empty((H, W), img.dtype)
         if minmax:
             out.minmax = self.empty((2,), np.float32)
-            L.check(self.lib.ma_warp_tiled_minmax(self.handle, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile),
-                                                  int(overlap), out.ptr, out.minmax.ptr))
+            self._run(self.lib.ma_warp_tiled_minmax, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile),
+                                                  int(overlap), out.ptr, out.minmax.ptr)
         else:
-            L.check(self.lib.ma_warp_tiled(self.handle, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile),
-                                           int(overlap), out.ptr))
+            self._run(self.lib.ma_warp_tiled, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile),
+                                           int(overlap), out.ptr)
         return out
 
     def warp_pages(self, pages, flow, tile, overlap, out=None):
@@ -248,7 +339,7 @@ class Context:
         n = len(pages)
         src = (C.c_void_p * n)(*[p.ctypes.data for p in pages])
         dst = (C.c_void_p * n)(*[o.ctypes.data for o in out])
-        L.check(self.lib.ma_warp_pages_host(self.handle, src, dst, n, dt, H, W, flow.ptr, int(tile), int(overlap)))
+        self._run(self.lib.ma_warp_pages_host, src, dst, n, dt, H, W, flow.ptr, int(tile), int(overlap))
         return out
 
     def merge_flows(self, flow1, flow2, tile, overlap):
@@ -257,8 +348,8 @@ class Context:
             raise ValueError("flows must have the same shape")
         H, W = flow1.shape[:2]
         out = self.empty((H, W, 2), np.float32)
-        L.check(self.lib.ma_merge_flows_tiled(self.handle, flow1.ptr, flow2.ptr, H, W, int(tile), int(overlap),
-                                              out.ptr))
+        self._run(self.lib.ma_merge_flows_tiled, flow1.ptr, flow2.ptr, H, W, int(tile), int(overlap),
+                                              out.ptr)
         return out
 
     def pyr_down(self, img, minmax=False):
@@ -266,9 +357,9 @@ class Context:
         out = self.empty(((h + 1) // 2, (w + 1) // 2), img.dtype)
         if minmax:
             out.minmax = self.empty((2,), np.float32)
-            L.check(self.lib.ma_pyr_down_minmax(self.handle, img.ptr, _dt(img.dtype), h, w, out.ptr, out.minmax.ptr))
+            self._run(self.lib.ma_pyr_down_minmax, img.ptr, _dt(img.dtype), h, w, out.ptr, out.minmax.ptr)
         else:
-            L.check(self.lib.ma_pyr_down(self.handle, img.ptr, _dt(img.dtype), h, w, out.ptr))
+            self._run(self.lib.ma_pyr_down, img.ptr, _dt(img.dtype), h, w, out.ptr)
         return out
 
     def pyr_up_flow(self, flow, dst_hw, scale=1.0):
@@ -276,12 +367,12 @@ class Context:
         h, w = flow.shape[:2]
         dh, dw = dst_hw
         out = self.empty((dh, dw, 2), np.float32)
-        L.check(self.lib.ma_pyr_up_flow(self.handle, flow.ptr, h, w, float(scale), out.ptr, int(dh), int(dw)))
+        self._run(self.lib.ma_pyr_up_flow, flow.ptr, h, w, float(scale), out.ptr, int(dh), int(dw))
         return out
 
     def minmax(self, arr):
         mn, mx = C.c_double(), C.c_double()
-        L.check(self.lib.ma_minmax(self.handle, arr.ptr, _dt(arr.dtype), arr.size, C.byref(mn), C.byref(mx)))
+        self._run(self.lib.ma_minmax, arr.ptr, _dt(arr.dtype), arr.size, C.byref(mn), C.byref(mx))
         return mn.value, mx.value
 
     def dog_u8(self, img, low_sigma=5, high_sigma=9, report_zero=False):
@@ -292,11 +383,11 @@ class Context:
         flag = C.c_int(0)
         fl = C.byref(flag) if report_zero else None
         if img.minmax is not None:   # the producing kernel already reduced the image
-            L.check(self.lib.ma_dog_u8_minmax(self.handle, img.ptr, _dt(img.dtype), h, w, int(low_sigma),
-                                              int(high_sigma), img.minmax.ptr, out.ptr, fl))
+            self._run(self.lib.ma_dog_u8_minmax, img.ptr, _dt(img.dtype), h, w, int(low_sigma),
+                                              int(high_sigma), img.minmax.ptr, out.ptr, fl)
         else:
-            L.check(self.lib.ma_dog_u8(self.handle, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma),
-                                       out.ptr, fl))
+            self._run(self.lib.ma_dog_u8, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma),
+                                       out.ptr, fl)
         return (out, bool(flag.value)) if report_zero else out
 
     def nmi_scores(self, a, b, chunk=0):
@@ -306,13 +397,13 @@ class Context:
         nch = 1 if (chunk <= 0 or chunk >= n) else (n + chunk - 1) // chunk
         scores = (C.c_double * nch)()
         got = C.c_int()
-        L.check(self.lib.ma_nmi_u8(self.handle, a.ptr, b.ptr, n, int(max(chunk, 0)), scores, nch, C.byref(got)))
+        self._run(self.lib.ma_nmi_u8, a.ptr, b.ptr, n, int(max(chunk, 0)), scores, nch, C.byref(got))
         return np.frombuffer(scores, dtype=np.float64, count=got.value).copy()
 
     def max_project(self, stack):
         nz = stack.shape[0]
         out = self.empty(stack.shape[1:], stack.dtype)
-        L.check(self.lib.ma_max_project(self.handle, stack.ptr, _dt(stack.dtype), nz, out.size, out.ptr))
+        self._run(self.lib.ma_max_project, stack.ptr, _dt(stack.dtype), nz, out.size, out.ptr)
         return out
 
     def warp_affine(self, img, inverse_3x3):
@@ -320,7 +411,7 @@ class Context:
         h, w = img.shape
         m = (C.c_double * 9)(*[float(v) for v in np.asarray(inverse_3x3, dtype=np.float64).ravel()])
         out = self.empty((h, w), img.dtype)
-        L.check(self.lib.ma_warp_affine(self.handle, img.ptr, _dt(img.dtype), h, w, m, out.ptr))
+        self._run(self.lib.ma_warp_affine, img.ptr, _dt(img.dtype), h, w, m, out.ptr)
         return out
 
     def warp_affine_cv(self, img, m2x3, dsize=None):
@@ -332,12 +423,12 @@ class Context:
             raise ValueError("the transform must be a 2x3 matrix")
         mm = (C.c_double * 6)(*[float(v) for v in m.ravel()])
         out = self.empty((dh, dw), img.dtype)
-        L.check(self.lib.ma_warp_affine_cv(self.handle, img.ptr, _dt(img.dtype), h, w, mm, dh, dw, out.ptr))
+        self._run(self.lib.ma_warp_affine_cv, img.ptr, _dt(img.dtype), h, w, mm, dh, dw, out.ptr)
         return out
 
     def normalize_minmax_u8(self, arr):
         out = self.empty(arr.shape, np.uint8)
-        L.check(self.lib.ma_normalize_minmax_u8(self.handle, arr.ptr, _dt(arr.dtype), arr.size, out.ptr))
+        self._run(self.lib.ma_normalize_minmax_u8, arr.ptr, _dt(arr.dtype), arr.size, out.ptr)
         return out
 
 
@@ -386,11 +477,11 @@ def get_context(device=None):
             n = C.c_int()
             lib = L.load()
             lib.ma_device_count(C.byref(n))
-            if n.value > 0:
-                device = device % n.value
-            ctx = _contexts.get(device)
-            if ctx is None:
-                ctx = _contexts[device] = Context(device)
+            if n.value > 0 and not 0 <= device < n.value:
+                # no silent wrap-around: a LOCAL_RANK beyond the visible devices would double-book a GPU
+                raise ValueError(f"HIP device index {device} is out of range: {n.value} device(s) visible "
+                                 "(MICROALIGNER_DEVICE / LOCAL_RANK select the device of this process)")
+            ctx = _contexts[device] = Context(device)
     return ctx
 
 

@@ -33,6 +33,15 @@
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Host threads for the row-parallel loops below (image rows, NMI chunks, Farneback windows are independent, so the
+ * results do not depend on this number).  Default 1. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
 
 #define ORC_U8 0
 #define ORC_U16 1
@@ -527,6 +536,7 @@ void orc_remap_tables(float* tab_f /*1024*4*/, short* tab_i /*1024*4*/)
 
 #define REMAP_BODY(T, WT, KT, LOADW, CASTEXPR) REMAP_BODY_X(T, WT, KT, LOADW, CASTEXPR, , COORDS_FROM_MAP)
 #define REMAP_BODY_X(T, WT, KT, LOADW, CASTEXPR, ROWSETUP, COORDS)                                  \
+    _Pragma("omp parallel for schedule(static) num_threads(g_threads)")                         \
     for (int y = 0; y < dh; y++) {                                                              \
         T* drow = (T*)dst + (size_t)y * dw * cn;                                                \
         ROWSETUP                                                                                \
@@ -640,9 +650,15 @@ int orc_pyr_down(const void* src, int dtype, int h, int w, void* dst)
     int dh = (h + 1) / 2, dw = (w + 1) / 2;
     if (dtype == ORC_F32) {
         const float* s = (const float*)src;
-        float* rows = (float*)malloc(sizeof(float) * (size_t)dw * 5);
-        if (!rows) return ORC_ENOMEM;
+        float* rows_all = (float*)malloc(sizeof(float) * (size_t)dw * 5 * g_threads);
+        if (!rows_all) return ORC_ENOMEM;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
         for (int y = 0; y < dh; y++) {
+#ifdef _OPENMP
+            float* rows = rows_all + (size_t)omp_get_thread_num() * dw * 5;
+#else
+            float* rows = rows_all;
+#endif
             for (int k = 0; k < 5; k++) {
                 const float* sr = s + (size_t)reflect101(2 * y + k - 2, h) * w;
                 float* r = rows + (size_t)k * dw;
@@ -659,13 +675,19 @@ int orc_pyr_down(const void* src, int dtype, int h, int w, void* dst)
             for (int x = 0; x < dw; x++)
                 d[x] = (r2[x] * 6 + (r1[x] + r3[x]) * 4 + r0[x] + r4[x]) * (1.f / 256);
         }
-        free(rows);
+        free(rows_all);
         return ORC_OK;
     }
     if (dtype != ORC_U8 && dtype != ORC_U16) return ORC_EINVAL;
-    int* rows = (int*)malloc(sizeof(int) * (size_t)dw * 5);
-    if (!rows) return ORC_ENOMEM;
+    int* rows_all = (int*)malloc(sizeof(int) * (size_t)dw * 5 * g_threads);
+    if (!rows_all) return ORC_ENOMEM;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int y = 0; y < dh; y++) {
+#ifdef _OPENMP
+        int* rows = rows_all + (size_t)omp_get_thread_num() * dw * 5;
+#else
+        int* rows = rows_all;
+#endif
         for (int k = 0; k < 5; k++) {
             size_t ro = (size_t)reflect101(2 * y + k - 2, h) * w;
             int* r = rows + (size_t)k * dw;
@@ -686,7 +708,7 @@ int orc_pyr_down(const void* src, int dtype, int h, int w, void* dst)
             else ((uint16_t*)dst)[(size_t)y * dw + x] = (uint16_t)clampi(v, 0, 65535);
         }
     }
-    free(rows);
+    free(rows_all);
     return ORC_OK;
 }
 
@@ -696,10 +718,17 @@ int orc_pyr_up_f32(const float* src, int cn, int h, int w, float* dst, int dh, i
     if (h <= 0 || w <= 0 || cn < 1) return ORC_EINVAL;
     if (abs(dw - w * 2) != dw % 2 || abs(dh - h * 2) != dh % 2) return ORC_EINVAL;
     int bufw = (dw + 1 > 2 * w ? dw + 1 : 2 * w) * cn;
-    float* buf = (float*)malloc(sizeof(float) * (size_t)bufw * 3);
-    if (!buf) return ORC_ENOMEM;
-    /* horizontal pass of source row sy into `row` (2w columns, +1 if dw > 2w) */
+    float* buf_all = (float*)malloc(sizeof(float) * (size_t)bufw * 3 * g_threads);
+    if (!buf_all) return ORC_ENOMEM;
+    /* horizontal pass of source row sy into `row` (2w columns, +1 if dw > 2w); source rows are independent
+     * (row y writes destination rows 2y and min(2y+1, dh-1); for the last y both may coincide, same thread) */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int y = 0; y < h; y++) {
+#ifdef _OPENMP
+        float* buf = buf_all + (size_t)omp_get_thread_num() * bufw * 3;
+#else
+        float* buf = buf_all;
+#endif
         float* rws[3];
         for (int k = 0; k < 3; k++) {
             int sy = y - 1 + k;
@@ -745,7 +774,7 @@ int orc_pyr_up_f32(const float* src, int cn, int h, int w, float* dst, int dh, i
         float* d2 = dst + (size_t)(h * 2) * dw * cn;
         for (int x = 0; x < dw * cn; x++) d2[x] = d0[x];
     }
-    free(buf);
+    free(buf_all);
     return ORC_OK;
 }
 
@@ -756,6 +785,7 @@ int orc_minmax(const void* src, int dtype, size_t n, double* mn, double* mx)
 {
     if (n == 0) return ORC_EINVAL;
     double lo = load_as_f32(src, dtype, 0), hi = lo;
+#pragma omp parallel for schedule(static) num_threads(g_threads) reduction(min : lo) reduction(max : hi)
     for (size_t i = 1; i < n; i++) {
         double v = load_as_f32(src, dtype, i);
         if (v < lo) lo = v;
@@ -776,6 +806,7 @@ int orc_normalize_minmax_to_f32(const void* src, int dtype, size_t n, double alp
     scale = (float)scale;
     double shift = (float)dmin - (float)(smin * scale);
     float a = (float)scale, b = (float)shift;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (size_t i = 0; i < n; i++) {
         float v = load_as_f32(src, dtype, i);
         float p = v * a;
@@ -793,6 +824,7 @@ int orc_normalize_minmax_f32_to_u8(const float* src, size_t n, uint8_t* dst)
     double scale = 255. * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
     double shift = 0. - smin * scale;
     float a = (float)scale, b = (float)shift;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (size_t i = 0; i < n; i++) {
         float p = src[i] * a;
         float v = p + b;
@@ -838,6 +870,7 @@ int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigm
     if (!k || !tmp) { free(k); free(tmp); return ORC_ENOMEM; }
     orc_gaussian_kernel(ksize, sigma, k);
     const int r = ksize / 2;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int y = 0; y < h; y++) {
         const float* s = src + (size_t)y * w;
         float* t = tmp + (size_t)y * w;
@@ -850,6 +883,7 @@ int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigm
             t[x] = acc;
         }
     }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int y = 0; y < h; y++) {
         float* d = dst + (size_t)y * w;
         const float* c = tmp + (size_t)y * w;
@@ -885,6 +919,7 @@ int orc_dog_u8(const void* src, int dtype, int h, int w, int low_sigma, int high
     if (rc) goto done;
     rc = orc_gaussian_blur_f32(fimg, h, w, ksize, high_sigma, hs);
     if (rc) goto done;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (size_t i = 0; i < n; i++) hs[i] = hs[i] - ls[i];
     rc = orc_normalize_minmax_f32_to_u8(hs, n, dst);
 done:
@@ -947,4 +982,24 @@ int orc_nmi_u8(const uint8_t* a, const uint8_t* b, size_t n, double* score)
     if (norm < DBL_EPSILON) norm = DBL_EPSILON;
     *score = mi / norm;
     return ORC_OK;
+}
+
+/* mi_tiled's loop (similarity_scoring.py:38-48): one score per contiguous chunk of `chunk` elements of the flattened
+ * arrays (the last chunk may be shorter), chunks fanned out over threads like the reference's dask tasks. */
+int orc_nmi_u8_chunks(const uint8_t* a, const uint8_t* b, size_t n, size_t chunk, double* scores, int nscores)
+{
+    if (n == 0 || chunk == 0) return ORC_EINVAL;
+    const size_t nch = (n + chunk - 1) / chunk;
+    if ((size_t)nscores < nch) return ORC_EINVAL;
+    int rc_all = ORC_OK;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (long long c = 0; c < (long long)nch; c++) {
+        const size_t o = (size_t)c * chunk, len = o + chunk <= n ? chunk : n - o;
+        int rc = orc_nmi_u8(a + o, b + o, len, scores + c);
+        if (rc) {
+#pragma omp critical
+            rc_all = rc;
+        }
+    }
+    return rc_all;
 }

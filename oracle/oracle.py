@@ -66,6 +66,11 @@ def lib():
         _lib.orc_dog_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib.orc_nmi_u8.restype = C.c_int
         _lib.orc_nmi_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]
+        _lib.orc_nmi_u8_chunks.restype = C.c_int
+        _lib.orc_nmi_u8_chunks.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int]
+        _lib.orc_set_threads.restype = None
+        _lib.orc_set_threads.argtypes = [C.c_int]
+        _lib.orc_get_threads.restype = C.c_int
         _lib.orc_farneback_window_kernel.restype = None
         _lib.orc_farneback_window_kernel.argtypes = [C.c_int, C.c_void_p]
         _lib.orc_farneback_prepare_gaussian.restype = C.c_int
@@ -78,6 +83,15 @@ def lib():
         _lib.orc_warp_affine_cv.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                             C.c_void_p]
     return _lib
+
+
+def set_threads(n):
+    """Host threads for the row / chunk / window loops of the oracle (results do not depend on it)."""
+    lib().orc_set_threads(int(n))
+
+
+def get_threads():
+    return lib().orc_get_threads()
 
 
 def _check(rc, what):
@@ -230,6 +244,18 @@ def nmi_u8(a, b):
     out = C.c_double()
     _check(lib().orc_nmi_u8(_p(a), _p(b), a.size, C.byref(out)), "nmi")
     return out.value
+
+
+def nmi_u8_chunks(a, b, chunk):
+    """One NMI score per contiguous `chunk`-element piece of the flattened arrays (mi_tiled's loop)."""
+    a = np.ascontiguousarray(a, dtype=np.uint8).ravel()
+    b = np.ascontiguousarray(b, dtype=np.uint8).ravel()
+    if a.size != b.size:
+        raise ValueError("size mismatch")
+    nch = -(-a.size // chunk)
+    scores = np.empty(nch, np.float64)
+    _check(lib().orc_nmi_u8_chunks(_p(a), _p(b), a.size, chunk, _p(scores), nch), "nmi_chunks")
+    return scores
 
 
 def farneback_window_kernel(winsize):

@@ -7,9 +7,23 @@ Pinned by tests/golden/*.npz, which were produced by driving the reference's own
 `cv2` stand-in -- see tests/golden/make_golden.py.  That pins tile geometry, level logic and the
 quirks Q1-Q3; the OpenCV arithmetic itself stays unpinned (ma_oracle.c header).
 """
+import time
+from contextlib import contextmanager
+
 import numpy as np
 
 from . import oracle as O
+
+
+@contextmanager
+def _stage(acc, name):
+    """Adds the wall time of the block to acc[name] (acc may be None): the per-stage seconds of the CPU baseline."""
+    t0 = time.perf_counter()
+    try:
+        yield
+    finally:
+        if acc is not None:
+            acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
 
 
 # ---- slicer.py:23-118 / stitcher.py:25-118 --------------------------------------------------------
@@ -86,10 +100,7 @@ def merge_flows(f1, f2, tile, overlap):
 def mi_tiled(a, b, tile):
     if max(a.shape) / tile < 2:
         return O.nmi_u8(a, b)
-    fa, fb = a.ravel(), b.ravel()
-    step = tile * tile
-    scores = [O.nmi_u8(fa[i:i + step], fb[i:i + step]) for i in range(0, fa.size, step)]
-    return np.mean(scores)
+    return np.mean(O.nmi_u8_chunks(a, b, tile * tile))
 
 
 # ---- optflow_registrator.py:175-215 -------------------------------------------------------------------
@@ -119,27 +130,42 @@ def upscale_to_full(flow, factor, full_shape):
 
 # ---- optflow_registrator.py:93-173 --------------------------------------------------------------------
 def register(ref, mov, num_pyr_lvl=4, num_iterations=3, tile_size=1000, overlap=100, use_full_res_img=False,
-             use_dog=False, fused=False, nthreads=1):
-    """Returns (flow, reports); reports = [(factor, mi_after, mi_before, accepted), ...]."""
+             use_dog=False, fused=False, nthreads=1, stage_seconds=None):
+    """Returns (flow, reports); reports = [(factor, mi_after, mi_before, accepted), ...].
+    stage_seconds: optional dict that receives the wall seconds per stage (pyramid, dog, farneback, warp, nmi,
+    merge_pyrup)."""
     win = overlap - (1 - overlap % 2)
-    ref_pyr, factors = image_pyramid(ref, num_pyr_lvl, use_full_res_img)
-    mov_pyr, _ = image_pyramid(mov, num_pyr_lvl, use_full_res_img)
+    O.set_threads(nthreads)  # rows / NMI chunks / Farneback windows fan out over host threads; same bits for any count
+    T = stage_seconds
+    with _stage(T, "pyramid"):
+        ref_pyr, factors = image_pyramid(ref, num_pyr_lvl, use_full_res_img)
+        mov_pyr, _ = image_pyramid(mov, num_pyr_lvl, use_full_res_img)
     n = len(factors)
     reports, m_flow = [], None
     for lvl, factor in enumerate(factors):
         last = lvl == n - 1
         mov_lvl = mov_pyr[lvl].copy()
         if lvl > 0:
-            mov_lvl = warp(mov_lvl, m_flow, tile_size, overlap)
-        this_flow = tile_flow(O.dog(ref_pyr[lvl], use_dog), O.dog(mov_lvl, use_dog), tile_size, overlap, win,
-                              num_iterations, fused=fused, nthreads=nthreads)
-        warped = warp(mov_lvl, this_flow, tile_size, overlap)
-        ref_d = O.dog(ref_pyr[lvl], True)
-        after = mi_tiled(ref_d, O.dog(warped, True), tile_size)
-        before = mi_tiled(ref_d, O.dog(mov_pyr[lvl], True), tile_size)
+            with _stage(T, "warp"):
+                mov_lvl = warp(mov_lvl, m_flow, tile_size, overlap)
+        with _stage(T, "dog"):
+            fb_ref, fb_mov = O.dog(ref_pyr[lvl], use_dog), O.dog(mov_lvl, use_dog)
+        with _stage(T, "farneback"):
+            this_flow = tile_flow(fb_ref, fb_mov, tile_size, overlap, win, num_iterations, fused=fused,
+                                  nthreads=nthreads)
+        del fb_ref, fb_mov
+        with _stage(T, "warp"):
+            warped = warp(mov_lvl, this_flow, tile_size, overlap)
+        with _stage(T, "dog"):
+            ref_d, warped_d, raw_d = O.dog(ref_pyr[lvl], True), O.dog(warped, True), O.dog(mov_pyr[lvl], True)
+        with _stage(T, "nmi"):
+            after = mi_tiled(ref_d, warped_d, tile_size)
+            before = mi_tiled(ref_d, raw_d, tile_size)
+        del ref_d, warped_d, raw_d, warped
         ok = bool(after > before)
         reports.append((factor, float(after), float(before), ok))
         nxt = None if last else mov_pyr[lvl + 1].shape
+        t_mp = time.perf_counter()
         if ok:
             if lvl == 0:
                 m_flow = O.pyr_up(this_flow * 2, dstsize=nxt[::-1]) if not last else \
@@ -158,4 +184,6 @@ def register(ref, mov, num_pyr_lvl=4, num_iterations=3, tile_size=1000, overlap=
                     m_flow = O.pyr_up(m_flow * 2, dstsize=ref.shape[::-1])
             else:
                 m_flow = O.pyr_up(m_flow * 4, dstsize=nxt[::-1])  # sic, Q3
+        if T is not None:
+            T["merge_pyrup"] = T.get("merge_pyrup", 0.0) + time.perf_counter() - t_mp
     return m_flow, reports

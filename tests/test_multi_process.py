@@ -43,3 +43,32 @@ def test_two_ranks_gloo(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.load(open(out))
     assert res == {"ok": True, "world": 2, "units": 5}
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must itself start two ranks (the launcher
+    never touches HIP), rendezvous them over gloo and report n_gpus: 2.  --dry-run skips the GPU work so that the
+    launch / barrier / max-reduce / JSON plumbing is testable here."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["config"]["pairs_per_step"] == 2
+
+
+def test_bench_launcher_propagates_a_rank_failure():
+    """Without a HIP device the ranks fail; the launcher must stop the survivors and exit non-zero, not hang."""
+    from microaligner_amd import device
+    try:
+        if device.device_count() > 0:
+            pytest.skip("a HIP device is present: the ranks would run the real benchmark")
+    except Exception:
+        pass
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--workload", "cfg1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
