@@ -338,7 +338,8 @@ def main():
         raise RuntimeError("no HIP device: the benchmark has no CPU path")
     # one process per GPU; on a box with fewer GPUs than ranks (the 1-GPU test box) ranks share devices, which the
     # JSON line states (`devices`)
-    ctx = get_context(local_rank % ndev)
+    os.environ["MICROALIGNER_DEVICE"] = str(local_rank % ndev)   # what get_context() inside register()/warp() picks up
+    ctx = get_context()
 
     np_dtype = np.uint8 if args.dtype == "u8" else np.float32
     ref, mov = synthetic.make_pair(H, W, seed=1 + rank, dtype=np_dtype)

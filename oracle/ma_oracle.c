@@ -870,19 +870,34 @@ int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigm
     if (!k || !tmp) { free(k); free(tmp); return ORC_ENOMEM; }
     orc_gaussian_kernel(ksize, sigma, k);
     const int r = ksize / 2;
+    /* row filter: acc = k[0]*s[x-r]; acc += k[j]*s[x-r+j] for j = 1..ksize-1, left to right.  The row is copied
+     * once into a reflect-101 padded buffer and the tap loop is the outer one, so that the inner loop runs over x
+     * on contiguous memory: per output pixel the operations and their order are unchanged. */
+    const int pw = w + 2 * r;
+    float* pad_all = (float*)malloc(sizeof(float) * (size_t)pw * g_threads);
+    if (!pad_all) { free(k); free(tmp); return ORC_ENOMEM; }
 #pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int y = 0; y < h; y++) {
+#ifdef _OPENMP
+        float* pad = pad_all + (size_t)omp_get_thread_num() * pw;
+#else
+        float* pad = pad_all;
+#endif
         const float* s = src + (size_t)y * w;
         float* t = tmp + (size_t)y * w;
-        for (int x = 0; x < w; x++) {
-            float acc = k[0] * s[reflect101(x - r, w)];
-            for (int j = 1; j < ksize; j++) {
-                float p = k[j] * s[reflect101(x - r + j, w)];
-                acc = acc + p;
+        for (int i = 0; i < pw; i++) pad[i] = s[reflect101(i - r, w)];
+        const float k0 = k[0];
+        for (int x = 0; x < w; x++) t[x] = k0 * pad[x];
+        for (int j = 1; j < ksize; j++) {
+            const float kj = k[j];
+            const float* pj = pad + j;
+            for (int x = 0; x < w; x++) {
+                float p = kj * pj[x];
+                t[x] = t[x] + p;
             }
-            t[x] = acc;
         }
     }
+    free(pad_all);
 #pragma omp parallel for schedule(static) num_threads(g_threads)
     for (int y = 0; y < h; y++) {
         float* d = dst + (size_t)y * w;

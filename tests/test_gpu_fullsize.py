@@ -1,0 +1,109 @@
+"""-m gpu: the hot path at BASELINE.json's FULL sizes against the CPU oracle, bit for bit.
+
+The oracle (oracle/, plain C + numpy orchestration) fans its Farneback windows, image rows and NMI chunks out over
+every host core (results do not depend on the thread count, tests/test_oracle_kat.py), which makes whole-image
+comparisons affordable on the GPU box: cfg2 (4096^2) in seconds, one cfg4 cycle (8192^2) and cfg3 (16384^2, DOG,
+5 levels, 405 Farneback windows) in a minute or two on its 100+ cores.  On a host with few cores the two large
+cases are skipped with a message (the sampled-window check of test_gpu_register.py still covers 16384^2 there).
+
+What is asserted at every size: the per-level accept / reject decisions, both MI scores of every level to 1e-12
+(which pins the DOG images, the warps and the NMI chunks of that level), the returned flow `array_equal` (which
+pins Farneback, merge and pyrUp of every level: any difference propagates into the final flow), and the warped
+image `array_equal`.
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle import register_oracle as RO
+from microaligner_amd import OptFlowRegistrator, Warper, synthetic
+
+pytestmark = pytest.mark.gpu
+CORES = os.cpu_count() or 1
+BIG_HOST = CORES >= int(os.environ.get("MA_FULLSIZE_MIN_CORES", "64"))
+
+
+def _hip(ref, mov, params):
+    reg = OptFlowRegistrator()
+    reg.verbose = False
+    for k, v in params.items():
+        setattr(reg, k, v)
+    reg.ref_img, reg.mov_img = ref, mov
+    flow = reg.register()
+    w = Warper()
+    w.tile_size, w.overlap = reg.tile_size, reg.overlap
+    w.image, w.flow = mov.copy(), flow
+    return flow, reg.level_reports, w.warp()
+
+
+def _compare(ref, mov, params, label):
+    t0 = time.perf_counter()
+    flow, reports, warped = _hip(ref, mov, params)
+    t1 = time.perf_counter()
+    exp_flow, exp_rep = RO.register(ref, mov, nthreads=CORES, **params)
+    exp_warp = RO.warp(mov, exp_flow, params.get("tile_size", 1000), params.get("overlap", 100))
+    t2 = time.perf_counter()
+    print(f"\n[{label}] HIP {t1 - t0:.2f} s (numpy in/out, cold), oracle {t2 - t1:.1f} s on {CORES} threads; levels "
+          f"{[(r.factor, r.accepted) for r in reports]}")
+    assert [r.factor for r in reports] == [r[0] for r in exp_rep]
+    assert [r.accepted for r in reports] == [r[3] for r in exp_rep]
+    np.testing.assert_allclose([(r.mi_after, r.mi_before) for r in reports], [(r[1], r[2]) for r in exp_rep],
+                               rtol=0, atol=1e-12)
+    assert flow.shape == exp_flow.shape and flow.dtype == np.float32
+    assert np.array_equal(flow, exp_flow), f"max |d| = {np.abs(flow - exp_flow).max()}"
+    assert warped.dtype == mov.dtype and np.array_equal(warped, exp_warp)
+    return flow
+
+
+def test_cfg2_register_and_warp_equal_the_oracle():
+    """BASELINE cfg2: 4096^2 float32, 3 Farneback levels [4, 2, 1] = 1 + 9 + 25 windows of 1200^2, no DOG input."""
+    ref, mov = synthetic.make_pair(4096, 4096, 2)
+    flow = _compare(ref, mov, dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=False), "cfg2 4096^2 f32")
+    dx, dy = synthetic.displacement(4096, 4096)
+    err = np.abs(flow[300:-300, 300:-300] - np.stack([dx + 0 * dy, dy + 0 * dx], -1)[300:-300, 300:-300])
+    assert err.mean() < 0.3
+
+
+@pytest.mark.skipif(not BIG_HOST, reason=f"the 8192^2 oracle run needs >= 64 host cores (this host: {CORES})")
+def test_cfg4_one_cycle_f32_equals_the_oracle():
+    """BASELINE cfg4, one cycle pair: 8192^2 float32, shipped YAML parameters (config_1.yaml:42-49:
+    num_pyr_lvl=3, use_full_res_img=True, use_dog=False) -> levels [8, 4, 2, 1] = 1 + 9 + 25 + 81 windows."""
+    ref, mov = synthetic.make_pair(8192, 8192, 4)
+    _compare(ref, mov, dict(num_pyr_lvl=3, use_full_res_img=True, use_dog=False), "cfg4 8192^2 f32")
+
+
+@pytest.mark.skipif(not BIG_HOST, reason=f"the 8192^2 oracle run needs >= 64 host cores (this host: {CORES})")
+def test_cfg4_one_cycle_pipeline_faithful_u8_equals_the_oracle(ctx):
+    """cfg4 as the pipeline feeds it (utils.py:75-95, __main__.py:418-424): the reference channel's z pages are
+    max-projected and min-max normalised to uint8 -- on the device here, numpy + oracle there -- and the uint8
+    images are registered."""
+    from microaligner_amd.shared_modules.utils import max_project_and_normalize
+    ref32, mov32 = synthetic.make_pair(8192, 8192, 5)
+    rng = np.random.default_rng(6)
+
+    def zstack(img):   # three z planes of one channel, uint16, the middle one in focus
+        planes = [np.clip(img * g * 200.0 + rng.normal(0, 30, img.shape).astype(np.float32), 0, 65535).astype(np.uint16)
+                  for g in (0.6, 1.0, 0.8)]
+        return np.stack(planes)
+
+    rs, ms = zstack(ref32), zstack(mov32)
+    del ref32, mov32
+    ref = max_project_and_normalize(rs)
+    mov = max_project_and_normalize(ms)
+    O.set_threads(CORES)
+    exp_ref = O.normalize_minmax_u8(np.maximum.reduce(list(rs)).astype(np.float32))
+    exp_mov = O.normalize_minmax_u8(np.maximum.reduce(list(ms)).astype(np.float32))
+    assert ref.dtype == np.uint8 and np.array_equal(ref, exp_ref) and np.array_equal(mov, exp_mov)
+    del rs, ms, exp_ref, exp_mov
+    _compare(ref, mov, dict(num_pyr_lvl=3, use_full_res_img=True, use_dog=False), "cfg4 8192^2 u8 (pipeline-faithful)")
+
+
+@pytest.mark.skipif(not BIG_HOST, reason=f"the 16384^2 oracle run needs >= 64 host cores (this host: {CORES})")
+def test_cfg3_register_and_warp_equal_the_oracle():
+    """BASELINE cfg3, the configuration the metric is quoted on: 16384^2 float32, DOG inputs, 5 levels
+    [16, 8, 4, 2, 1] = 1 + 9 + 25 + 81 + 289 windows, 269-chunk NMI gate, 289-window merge, pyrUp to 16384^2."""
+    ref, mov = synthetic.make_pair(16384, 16384, 1)
+    _compare(ref, mov, dict(num_pyr_lvl=4, use_full_res_img=True, use_dog=True), "cfg3 16384^2 f32 + DOG")
