@@ -216,7 +216,10 @@ def host_inclusive_leg(steps, ref, mov, params):
         w.image, w.flow = mov, flow
         return flow, w.warp()
 
-    one()
+    # two untimed passes bound to the same names as the timed loop: the page-locked result pool reaches its steady
+    # state (two flow-sized buffers alternate, the previous result is still referenced while the next one is made)
+    flow, warped = one()
+    flow, warped = one()
     t0 = time.perf_counter()
     for _ in range(steps):
         flow, warped = one()

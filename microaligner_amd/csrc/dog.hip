@@ -8,6 +8,7 @@
 // normalisation scalars are derived on the device from the reduced min/max exactly as OpenCV derives them.
 #include "ma_internal.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -151,12 +152,12 @@ int minmax_host(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn, d
     return MA_OK;
 }
 
-// ---- DOG row pass -----------------------------------------------------------------------------
+// ---- DOG row pass, any kernel size (the fallback chain for sizes other than the reference's 41) ----------
 // Block: 256 output columns x DR rows.  The normalised input row segment (+- r halo, reflect-101) is staged in
-// LDS; every thread accumulates both kernels left to right over the ksize taps (one LDS read per tap, shared).
+// LDS; a thread produces 4 consecutive columns of one row, accumulating both kernels left to right over the
+// ksize taps (acc = k0*v0, then acc = acc + k_j*v_j for ascending j).
 constexpr int DR = 4;
-// KS: compile-time kernel size of the register-window fast path (0: any size, one LDS read per tap)
-template <typename T, int KS>
+template <typename T>
 __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h, int w, int ksize,
                                                 const DogScalars* __restrict__ sc, const float* __restrict__ klh,
                                                 float* __restrict__ tlo, float* __restrict__ thi)
@@ -165,92 +166,26 @@ __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h
     const int r = ksize / 2, span = 256 + 2 * r;
     const int x0 = blockIdx.x * 256, y0 = blockIdx.y * DR;
     const float a = sc->a, b = sc->b;
-    // column indices once per thread (a thread stages columns tid and tid + 256 of every row); all loads of the
-    // block are issued before the first LDS store
-    const int c1 = threadIdx.x + 256;
-    const int xa = d_reflect101(x0 - r + (int)threadIdx.x, w), xb = d_reflect101(x0 - r + min(c1, span - 1), w);
-    {
-        float va[DR], vb[DR];
-#pragma unroll
-        for (int row = 0; row < DR; row++) {
-            const T* s = src + (size_t)min(y0 + row, h - 1) * w;
-            va[row] = (float)s[xa];
-            vb[row] = (float)s[xb];
-        }
-        // copy A: lds[row][c] = v[c]; copy B (offset DR * span + 64): the same row shifted by one element,
-        // B[row][c] = v[c + 1], so that the odd-offset input pairs of the row pass are aligned 16-byte reads too
-        float* ldb = lds + DR * span + 64;
-#pragma unroll
-        for (int row = 0; row < DR; row++) {
-            const float fa = __fadd_rn(__fmul_rn(va[row], a), b), fb = __fadd_rn(__fmul_rn(vb[row], a), b);
-            lds[row * span + threadIdx.x] = fa;
-            if (threadIdx.x > 0) ldb[row * span + threadIdx.x - 1] = fa;
-            if (c1 < span) { lds[row * span + c1] = fb; ldb[row * span + c1 - 1] = fb; }
-        }
+    for (int row = 0; row < DR; row++) {
+        const T* s = src + (size_t)min(y0 + row, h - 1) * w;
+        for (int c = threadIdx.x; c < span; c += 256)
+            lds[row * span + c] = __fadd_rn(__fmul_rn((float)s[d_reflect101(x0 - r + c, w)], a), b);
     }
     __syncthreads();
-    // A thread produces 4 consecutive columns of ONE row (wave = row) as two register pairs per sigma,
-    // (out0, out1) and (out2, out3).  Its ksize + 3 inputs come from LDS as 16-byte reads, once as the aligned
-    // pairs E[q] = (v[2q], v[2q+1]) and once, from the shifted copy, as O[q] = (v[2q+1], v[2q+2]): tap j multiplies
-    // the pair starting at v[j] (E or O by parity) by the tap broadcast from an SGPR -- packed math with no
-    // register shuffles, 2 packed ops per output and tap, and a quarter of the LDS instructions of one read per
-    // tap.  Per output: acc = k0*v0, then acc = acc + k_j*v_j for ascending j, exactly the scalar order.
     const int row = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int y = y0 + row, x = x0 + 4 * lane;
     if (y >= h || x >= w) return;
     const ma_f2* __restrict__ kk = reinterpret_cast<const ma_f2*>(klh);   // klh[j] = (k_lo[j], k_hi[j])
-    ma_f2 acc[4];
-    if constexpr (KS > 0) {
-        constexpr int KMAX = (KS + 3 + 3) / 4 * 4;  // inputs per thread, rounded up to whole 16-byte reads
-        ma_f2 E[KMAX / 2], O[KMAX / 2];
-        const float4* a4 = reinterpret_cast<const float4*>(lds + row * span + 4 * lane);
-        const float4* b4 = reinterpret_cast<const float4*>(lds + DR * span + 64 + row * span + 4 * lane);
 #pragma unroll
-        for (int q = 0; q < KMAX / 4; q++) {
-            // reads past ksize + 3 stay inside the block's LDS allocation (next row or tail pad) and are not used
-            const float4 t = a4[q], u = b4[q];
-            E[2 * q] = (ma_f2){t.x, t.y}; E[2 * q + 1] = (ma_f2){t.z, t.w};
-            O[2 * q] = (ma_f2){u.x, u.y}; O[2 * q + 1] = (ma_f2){u.z, u.w};
+    for (int o = 0; o < 4; o++) {
+        const float* v = lds + row * span + 4 * lane + o;   // columns past the image stay inside the staged span
+        ma_f2 s2 = kk[0] * (ma_f2){v[0], v[0]};
+        for (int j = 1; j < ksize; j++) {
+            const float vj = v[j];
+            const ma_f2 p = kk[j] * (ma_f2){vj, vj};
+            s2 = s2 + p;
         }
-        ma_f2 lo01, lo23, hi01, hi23;
-        {
-            const ma_f2 k = kk[0];
-            const ma_f2 kl = {k.x, k.x}, kh = {k.y, k.y};
-            lo01 = E[0] * kl; lo23 = E[1] * kl; hi01 = E[0] * kh; hi23 = E[1] * kh;
-        }
-#pragma unroll
-        for (int j = 1; j < KS; j++) {
-            const ma_f2 k = kk[j];
-            const ma_f2 kl = {k.x, k.x}, kh = {k.y, k.y};
-            const ma_f2 d01 = (j & 1) ? O[(j - 1) / 2] : E[j / 2];
-            const ma_f2 d23 = (j & 1) ? O[(j - 1) / 2 + 1] : E[j / 2 + 1];
-            lo01 = lo01 + d01 * kl; lo23 = lo23 + d23 * kl;
-            hi01 = hi01 + d01 * kh; hi23 = hi23 + d23 * kh;
-        }
-        acc[0] = (ma_f2){lo01.x, hi01.x}; acc[1] = (ma_f2){lo01.y, hi01.y};
-        acc[2] = (ma_f2){lo23.x, hi23.x}; acc[3] = (ma_f2){lo23.y, hi23.y};
-    } else {
-#pragma unroll
-        for (int o = 0; o < 4; o++) {
-            const float* v = lds + row * span + 4 * lane + o;   // columns past the image stay inside the staged span
-            ma_f2 s2 = kk[0] * (ma_f2){v[0], v[0]};
-            for (int j = 1; j < ksize; j++) {
-                const float vj = v[j];
-                const ma_f2 p = kk[j] * (ma_f2){vj, vj};
-                s2 = s2 + p;
-            }
-            acc[o] = s2;
-        }
-    }
-    float* plo = tlo + (size_t)y * w + x;
-    float* phi = thi + (size_t)y * w + x;
-    if (x + 3 < w && (w & 3) == 0) {
-        *reinterpret_cast<float4*>(plo) = make_float4(acc[0].x, acc[1].x, acc[2].x, acc[3].x);
-        *reinterpret_cast<float4*>(phi) = make_float4(acc[0].y, acc[1].y, acc[2].y, acc[3].y);
-    } else {
-#pragma unroll
-        for (int o = 0; o < 4; o++)
-            if (x + o < w) { plo[o] = acc[o].x; phi[o] = acc[o].y; }
+        if (x + o < w) { tlo[(size_t)y * w + x + o] = s2.x; thi[(size_t)y * w + x + o] = s2.y; }
     }
 }
 
@@ -319,6 +254,159 @@ __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict
         part[bid * 2] = lo;
         part[bid * 2 + 1] = hi;
     }
+}
+
+// ---- fused DOG: row pass -> LDS -> column pass -> difference + block min/max (ksize 41, the reference's sigmas) ----
+// One block owns a 64-column strip and streams down LY rows of it.  The row-filtered rows of both sigmas live in
+// LDS (CB, [sigma][rows][64]); per super-step of S = NW*R output rows the block
+//   1. stages 2 x 32 normalised input rows (+-20 halo columns, reflect-101) and row-filters them into CB rows
+//      [CARRY, CARRY + S)  -- same register-pair scheme as dog_rows: 4 outputs per thread from 16-byte LDS reads of
+//      the row (copy A) and the row shifted by one element (copy B), taps broadcast from SGPRs;
+//   2. runs the symmetric column filter for both sigmas from CB (d_sym_fir_slide_pk, as dog_cols_diff), writes
+//      hs - ls and folds the min / max;
+//   3. moves the last CARRY = 2r + 2 rows of CB to the top: they are the halo of the next super-step.
+// The two intermediate images of the unfused chain (8 B/px written and read back) never reach HBM: per pixel the
+// kernel reads the source once (+ the halo columns its neighbour strip also reads, served by L2) and writes
+// 4 bytes.  Per output the operations and their order are those of dog_rows / dog_cols_diff: bit-identical.
+// The global loads of the next chunk are issued before the row filter of the current one (register prefetch).
+constexpr int DF_NW = 8, DF_R = 8, DF_S = DF_NW * DF_R;   // 64 output rows per super-step
+constexpr int DF_KS = 41, DF_RAD = 20, DF_G = 1;          // guard row: d_sym_fir_slide_pk loads [jb-m-1, jb+R+m]
+constexpr int DF_CARRY = 2 * DF_RAD + 2 * DF_G;           // 42
+constexpr int DF_CBROWS = DF_S + DF_CARRY;                // 106
+constexpr int DF_CH = 32;                                 // rows per row-filter chunk (512 threads x 4 columns)
+constexpr int DF_SP = 64 + 2 * DF_RAD;                    // 104 staged columns per row (16-byte multiple)
+constexpr size_t DF_LDS = (size_t)(2 * DF_CH * DF_SP + 2 * DF_CBROWS * 64) * sizeof(float);  // 80 896 B: 2 blocks / CU
+
+template <typename T>
+__global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__ src, int h, int w, int LY, int nstrips,
+                                                          int nseg, const DogScalars* __restrict__ sc,
+                                                          const float* __restrict__ klh, const float* __restrict__ klo_c,
+                                                          const float* __restrict__ khi_c, float* __restrict__ diff,
+                                                          float* __restrict__ part)
+{
+    extern __shared__ float lds[];
+    float* A = lds;                         // [DF_CH][DF_SP]   A[row][c] = v[c]
+    float* B = A + DF_CH * DF_SP;           // [DF_CH][DF_SP]   B[row][c] = v[c + 1]
+    float* CB = B + DF_CH * DF_SP;          // [2][DF_CBROWS][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // strips fastest: neighbouring strips (which share 40 of their 104 input columns) are consecutive items of one XCD
+    const int item = d_xcd_work_item(blockIdx.x, nstrips * nseg);
+    if (item >= nstrips * nseg) return;
+    const int strip = item % nstrips, seg = item / nstrips;
+    const int x0 = strip * 64, Y0 = seg * LY, Y1 = min(h, Y0 + LY);
+    const float a = sc->a, b = sc->b;
+    const int xa = d_reflect101(x0 - DF_RAD + lane, w);
+    const int xb = d_reflect101(x0 - DF_RAD + 64 + min(lane, 2 * DF_RAD - 1), w);
+
+    float va[4], vb[4];
+    // wave wv stages rows 4 wv .. 4 wv + 3 of the chunk whose first row is global row g0 (reflect-101 in y)
+    auto load_chunk = [&](int g0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const T* srow = src + (size_t)d_reflect101(g0 + wv * 4 + k, h) * w;
+            va[k] = (float)srow[xa];
+            vb[k] = (float)srow[xb];
+        }
+    };
+    auto commit_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int row = wv * 4 + k;
+            const float fa = __fadd_rn(__fmul_rn(va[k], a), b), fb = __fadd_rn(__fmul_rn(vb[k], a), b);
+            A[row * DF_SP + lane] = fa;
+            if (lane > 0) B[row * DF_SP + lane - 1] = fa;
+            if (lane < 2 * DF_RAD) { A[row * DF_SP + 64 + lane] = fb; B[row * DF_SP + 63 + lane] = fb; }
+        }
+    };
+    // row filter of the staged chunk into CB rows [cb0, cb0 + nrows): thread = 4 consecutive columns of one row
+    const int rrow = tid >> 4, rq = tid & 15;
+    const ma_f2* __restrict__ kk = reinterpret_cast<const ma_f2*>(klh);   // klh[j] = (k_lo[j], k_hi[j])
+    auto row_filter = [&](int cb0, int nrows) {
+        if (rrow >= nrows) return;
+        constexpr int KMAX = (DF_KS + 3 + 3) / 4 * 4;   // 44 inputs per thread
+        ma_f2 E[KMAX / 2], O[KMAX / 2];
+        const float4* a4 = reinterpret_cast<const float4*>(A + rrow * DF_SP + 4 * rq);
+        const float4* b4 = reinterpret_cast<const float4*>(B + rrow * DF_SP + 4 * rq);
+#pragma unroll
+        for (int q = 0; q < KMAX / 4; q++) {
+            const float4 t = a4[q], u = b4[q];
+            E[2 * q] = (ma_f2){t.x, t.y}; E[2 * q + 1] = (ma_f2){t.z, t.w};
+            O[2 * q] = (ma_f2){u.x, u.y}; O[2 * q + 1] = (ma_f2){u.z, u.w};
+        }
+        ma_f2 lo01, lo23, hi01, hi23;
+        {
+            const ma_f2 k = kk[0];
+            const ma_f2 kl = {k.x, k.x}, kh = {k.y, k.y};
+            lo01 = E[0] * kl; lo23 = E[1] * kl; hi01 = E[0] * kh; hi23 = E[1] * kh;
+        }
+#pragma unroll
+        for (int j = 1; j < DF_KS; j++) {
+            const ma_f2 k = kk[j];
+            const ma_f2 kl = {k.x, k.x}, kh = {k.y, k.y};
+            const ma_f2 d01 = (j & 1) ? O[(j - 1) / 2] : E[j / 2];
+            const ma_f2 d23 = (j & 1) ? O[(j - 1) / 2 + 1] : E[j / 2 + 1];
+            lo01 = lo01 + d01 * kl; lo23 = lo23 + d23 * kl;
+            hi01 = hi01 + d01 * kh; hi23 = hi23 + d23 * kh;
+        }
+        float* clo = CB + (cb0 + rrow) * 64 + 4 * rq;
+        *reinterpret_cast<float4*>(clo) = make_float4(lo01.x, lo01.y, lo23.x, lo23.y);
+        *reinterpret_cast<float4*>(clo + DF_CBROWS * 64) = make_float4(hi01.x, hi01.y, hi23.x, hi23.y);
+    };
+
+    float lo = INFINITY, hi = -INFINITY;
+    const int gtop = Y0 - DF_RAD - DF_G;      // global row held by CB row 0 during the first super-step
+    // prologue: CB rows [0, CARRY)
+    load_chunk(gtop);
+    commit_chunk();
+    __syncthreads();
+    load_chunk(gtop + DF_CH);
+    row_filter(0, DF_CH);
+    __syncthreads();
+    commit_chunk();
+    __syncthreads();
+    load_chunk(gtop + DF_CARRY);
+    row_filter(DF_CH, DF_CARRY - DF_CH);
+    __syncthreads();
+    for (int ys = Y0; ys < Y1; ys += DF_S) {
+        const int g = ys - DF_RAD - DF_G;     // global row of CB row 0
+        commit_chunk();                        // rows g + CARRY .. + 31
+        __syncthreads();
+        load_chunk(g + DF_CARRY + DF_CH);
+        row_filter(DF_CARRY, DF_CH);
+        __syncthreads();
+        commit_chunk();                        // rows g + CARRY + 32 .. + 63
+        __syncthreads();
+        if (ys + DF_S < Y1) load_chunk(g + DF_S + DF_CARRY);   // first chunk of the next super-step
+        row_filter(DF_CARRY + DF_CH, DF_CH);
+        __syncthreads();
+        {
+            float sl[DF_R], sh[DF_R];
+            d_sym_fir_slide_pk<DF_R, false, true>(CB + lane, DF_G + DF_RAD + wv * DF_R, DF_RAD, klo_c, sl);
+            d_sym_fir_slide_pk<DF_R, false, true>(CB + DF_CBROWS * 64 + lane, DF_G + DF_RAD + wv * DF_R, DF_RAD, khi_c, sh);
+            const int x = x0 + lane;
+#pragma unroll
+            for (int q = 0; q < DF_R; q++) {
+                const int y = ys + wv * DF_R + q;
+                if (x < w && y < Y1) {
+                    const float d = sh[q] - sl[q];
+                    diff[(size_t)y * w + x] = d;
+                    lo = fminf(lo, d); hi = fmaxf(hi, d);
+                }
+            }
+        }
+        __syncthreads();
+        if (ys + DF_S < Y1) {
+            // the halo of the next super-step: CB rows [S, S + CARRY) -> [0, CARRY) (disjoint, S >= CARRY)
+            for (int e = tid; e < 2 * DF_CARRY * 16; e += 64 * DF_NW) {
+                const int sg = e / (DF_CARRY * 16), rem = e - sg * (DF_CARRY * 16);
+                float4* base = reinterpret_cast<float4*>(CB + sg * DF_CBROWS * 64);
+                base[rem] = base[DF_S * 16 + rem];
+            }
+            __syncthreads();
+        }
+    }
+    d_block_minmax(lo, hi, part + (size_t)item * 2);
 }
 
 // dst = saturate_u8(round_half_even(src*a + b)); a/b either immediate or from the DOG scalars.
@@ -423,7 +511,7 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
     const size_t n = (size_t)h * w;
     const int ksize = low_sigma * 4 * 2 + 1;  // optflow_registrator.py:262
     const int r = ksize / 2;
-    const size_t lds_rows = 2 * ((size_t)DR * (256 + 2 * r) + 64) * sizeof(float);  // two copies (+ tail pad for the 16-byte reads)
+    const size_t lds_rows = (size_t)DR * (256 + 2 * r) * sizeof(float);
     const int DC_R = (r % 10 == 0) ? 10 : 16;
     const size_t lds_cols = (size_t)(DC_NW * DC_R + 2 * r + 4) * 64 * sizeof(float);
     MA_REQUIRE(lds_rows <= 160 * 1024 && lds_cols <= 160 * 1024, "low_sigma too large for the LDS-staged DOG kernels");
@@ -443,15 +531,28 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
     MA_TRY(ma_const_table(ctx, ((uint64_t)3 << 56) | key | (uint64_t)low_sigma, clo.data(), clo.size(), &dloc));
     MA_TRY(ma_const_table(ctx, ((uint64_t)3 << 56) | key | (uint64_t)high_sigma, chi.data(), chi.size(), &dhic));
 
-    // workspace: tlo, thi, diff (f32 each), block partials, scalars
+    // The reference's kernel size (41: sigmas 5 / 9) takes the fused kernel; other sizes the two-kernel chain.
+    const bool fused = ksize == DF_KS;
+    const int nstrips = (w + 63) / 64;
+    // rows per block: enough blocks to fill 256 CUs x 2 a few times over, few enough that the 42 halo rows a block
+    // filters before its first output row stay a small fraction
+    int LY = h;
+    {
+        const int want_seg = std::max(1, 1536 / nstrips);
+        LY = (int)ma_align_up((size_t)std::max(1, (h + want_seg - 1) / want_seg), DF_S);
+        if (LY < 4 * DF_S) LY = std::min(4 * DF_S, (int)ma_align_up((size_t)h, DF_S));
+    }
+    const int nseg = (h + LY - 1) / LY;
+    // workspace: [tlo, thi,] diff (f32 each), block partials, scalars
     const dim3 cgrid((w + 63) / 64, (h + DC_NW * DC_R - 1) / (DC_NW * DC_R));
-    const size_t nblk = (size_t)cgrid.x * cgrid.y;
+    const size_t nblk = fused ? (size_t)nstrips * nseg : (size_t)cgrid.x * cgrid.y;
     const size_t npart = nblk > MM_BLOCKS ? nblk : MM_BLOCKS;
-    const size_t bytes = n * 3 * sizeof(float) + npart * 2 * sizeof(float) + 256 + 16;
+    const size_t nimg = fused ? 1 : 3;
+    const size_t bytes = n * nimg * sizeof(float) + npart * 2 * sizeof(float) + 256 + 16;
     MA_TRY(ma_ws_reserve(ctx, bytes));
     float* tlo = (float*)ctx->ws;
     float* thi = tlo + n;
-    float* diff = thi + n;
+    float* diff = fused ? (float*)ctx->ws : thi + n;
     float* part = (float*)ma_align_up((size_t)(diff + n), 16);  // read as float2 pairs by minmax_final
     DogScalars* sc = (DogScalars*)(part + npart * 2);
     MA_REQUIRE((h + DR - 1) / DR <= 65535, "image too tall");
@@ -463,26 +564,29 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
         MA_TRY(launch_minmax(ctx, src, dtype, n, part, sc->mm_src));
     }
     hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc);
-    {
-        dim3 grid((w + 255) / 256, (h + DR - 1) / DR), block(256);
-#define MA_DOG_ROWS(T, KS) hipLaunchKernelGGL((dog_rows<T, KS>), grid, block, lds_rows, ctx->stream, (const T*)src, h, w, ksize, sc, dlo, tlo, thi)
-        if (ksize == 41) {  // the reference's sigmas (5, 9): register-window path
-            if (dtype == MA_U8) MA_DOG_ROWS(uint8_t, 41);
-            else if (dtype == MA_U16) MA_DOG_ROWS(uint16_t, 41);
-            else MA_DOG_ROWS(float, 41);
-        } else {
-            if (dtype == MA_U8) MA_DOG_ROWS(uint8_t, 0);
-            else if (dtype == MA_U16) MA_DOG_ROWS(uint16_t, 0);
-            else MA_DOG_ROWS(float, 0);
-        }
+    if (fused) {
+        const dim3 grid(ma_xcd_grid((long long)nblk)), block(64 * DF_NW);
+#define MA_DOG_FUSED(T) hipLaunchKernelGGL((dog_fused<T>), grid, block, DF_LDS, ctx->stream, (const T*)src, h, w, LY, nstrips, nseg, sc, dlo, dloc, dhic, diff, part)
+        if (dtype == MA_U8) MA_DOG_FUSED(uint8_t);
+        else if (dtype == MA_U16) MA_DOG_FUSED(uint16_t);
+        else MA_DOG_FUSED(float);
+#undef MA_DOG_FUSED
+    } else {
+        {
+            dim3 grid((w + 255) / 256, (h + DR - 1) / DR), block(256);
+#define MA_DOG_ROWS(T) hipLaunchKernelGGL((dog_rows<T>), grid, block, lds_rows, ctx->stream, (const T*)src, h, w, ksize, sc, dlo, tlo, thi)
+            if (dtype == MA_U8) MA_DOG_ROWS(uint8_t);
+            else if (dtype == MA_U16) MA_DOG_ROWS(uint16_t);
+            else MA_DOG_ROWS(float);
 #undef MA_DOG_ROWS
+        }
+        if (DC_R == 10)
+            hipLaunchKernelGGL((dog_cols_diff<10, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
+                               ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
+        else
+            hipLaunchKernelGGL((dog_cols_diff<16, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
+                               ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
     }
-    if (DC_R == 10)
-        hipLaunchKernelGGL((dog_cols_diff<10, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
-                           ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
-    else
-        hipLaunchKernelGGL((dog_cols_diff<16, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
-                           ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
     hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, (int)nblk, sc->mm_diff);
     hipLaunchKernelGGL(dog_params_out, dim3(1), dim3(1), 0, ctx->stream, sc);
     hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst);

@@ -197,13 +197,19 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
 }
 
 // ---- flow merge ---------------------------------------------------------------------------------
-// per window: max over the zero-padded window of both flow components (numpy .max(), NaNs ignored)
-// floats <-> unsigned keys whose integer order is the float order (so atomicMax works for any sign)
+// per window: max over the zero-padded window of both flow components with numpy's .max() semantics: a NaN
+// anywhere in the window makes the maximum NaN, `nan == 0` is False and the window takes the general remap branch
+// (optflow_registrator.py:38-47).
+// floats <-> unsigned keys whose integer order is the float order (so atomicMax works for any sign); every NaN maps
+// to the largest key, so it survives the atomic reduction
 __device__ __forceinline__ unsigned f2key(float f)
 {
+    if (f != f) return 0xffffffffu;
     unsigned u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+// NaN-propagating maximum (fmaxf drops NaNs)
+__device__ __forceinline__ float d_max_nan(float m, float v) { return (m != m || v != v) ? NAN : fmaxf(m, v); }
 __device__ __forceinline__ float key2f(unsigned k)
 {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
@@ -228,12 +234,12 @@ __global__ __launch_bounds__(256) void window_max_kernel(const float2* __restric
     for (int yy = ya + (threadIdx.x >> 6); yy < ye; yy += 4)
         for (int xx = xa + (threadIdx.x & 63); xx < xb; xx += 64) {
             float2 a = f1[(size_t)yy * g.W + xx], b = f2[(size_t)yy * g.W + xx];
-            m1 = fmaxf(m1, fmaxf(a.x, a.y));
-            m2 = fmaxf(m2, fmaxf(b.x, b.y));
+            m1 = d_max_nan(m1, d_max_nan(a.x, a.y));
+            m2 = d_max_nan(m2, d_max_nan(b.x, b.y));
         }
     for (int off = 32; off > 0; off >>= 1) {
-        m1 = fmaxf(m1, __shfl_down(m1, off));
-        m2 = fmaxf(m2, __shfl_down(m2, off));
+        m1 = d_max_nan(m1, __shfl_down(m1, off));
+        m2 = d_max_nan(m2, __shfl_down(m2, off));
     }
     if ((threadIdx.x & 63) == 0) {
         atomicMax(&maxkeys[widx * 2], f2key(m1));
@@ -271,12 +277,12 @@ __global__ __launch_bounds__(256) void cell_max_kernel(const float2* __restrict_
     for (int yy = ya + (threadIdx.x >> 6); yy < yb; yy += 4)
         for (int xx = xa + (threadIdx.x & 63); xx < xb; xx += 64) {
             const float2 a = f1[(size_t)yy * g.W + xx], b = f2[(size_t)yy * g.W + xx];
-            m1 = fmaxf(m1, fmaxf(a.x, a.y));
-            m2 = fmaxf(m2, fmaxf(b.x, b.y));
+            m1 = d_max_nan(m1, d_max_nan(a.x, a.y));
+            m2 = d_max_nan(m2, d_max_nan(b.x, b.y));
         }
     for (int off = 32; off > 0; off >>= 1) {
-        m1 = fmaxf(m1, __shfl_down(m1, off));
-        m2 = fmaxf(m2, __shfl_down(m2, off));
+        m1 = d_max_nan(m1, __shfl_down(m1, off));
+        m2 = d_max_nan(m2, __shfl_down(m2, off));
     }
     if ((threadIdx.x & 63) == 0) {
         unsigned* c = cellkeys + ((size_t)segy * nsegx + blockIdx.x) * 2;

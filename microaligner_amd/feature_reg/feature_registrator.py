@@ -14,6 +14,7 @@ import numpy as np
 from ..device import DeviceArray, get_context
 from ..shared_modules.img_checks import check_img_dims_match, check_img_is_2d_grey, check_img_is_provided
 from ..shared_modules.similarity_scoring import check_if_higher_similarity
+from . import affine_math
 from .feature_detection import Features
 from .tile_registration import find_features, register_img_pair
 
@@ -164,45 +165,16 @@ class FeatureRegistrator:
     def _realign_img(self, mov_img, mat_list):
         return self.transform_img(mov_img, self._multiply_transform_matrices(mat_list))
 
-    # -- matrix bookkeeping ----------------------------------------------------------------------------------------
+    # -- matrix bookkeeping (feature_reg/affine_math.py) ---------------------------------------------------------
     def _multiply_transform_matrices(self, mat_list):
-        """:214-222: product of the homogeneous matrices, first matrix leftmost."""
-        if len(mat_list) == 1:
-            return mat_list[0]
-        res = np.append(mat_list[0], [[0, 0, 1]], axis=0)
-        for m in mat_list[1:]:
-            res = res @ np.append(m, [[0, 0, 1]], axis=0)
-        return res[:2, :]
+        return affine_math.compose(mat_list)
 
     def _rescale_t_mat(self, t_mat, scale: float):
-        out = np.array(t_mat, dtype=np.float64, copy=True)
-        out[0, 2] *= scale
-        out[1, 2] *= scale
-        return out
+        return affine_math.with_translation_scaled(t_mat, scale)
 
     def _check_if_valid_transform(self, t_mat, img_shape) -> bool:
-        return bool(self._check_if_inside_borders(t_mat, img_shape) and self._check_if_proper_scale(t_mat))
-
-    def _check_if_proper_scale(self, t_mat) -> bool:
-        """:241-266: QR-like decomposition of the linear part; both scale factors must lie in [0.3, 3]."""
-        a, b, c, d = t_mat[0, 0], t_mat[1, 0], t_mat[0, 1], t_mat[1, 1]
-        det = a * d - b * c
-        if a != 0 or b != 0:
-            r = np.sqrt(a ** 2 + b ** 2)
-            scale = (r, det / r)
-        elif c != 0 or d != 0:
-            s = np.sqrt(c ** 2 + d ** 2)
-            scale = (det / s, s)
-        else:
-            return False
-        return all(0.3 <= abs(s) <= 3 for s in scale)
-
-    def _check_if_inside_borders(self, t_mat, img_shape) -> bool:
-        """:268-279: the transformed image centre must stay inside the image extent."""
-        centre = np.array([[img_shape[1] // 2], [img_shape[0] // 2], [1]])
-        border = np.array([[img_shape[1]], [img_shape[0]], [1]])
-        moved = np.append(t_mat, [[0, 0, 1]], axis=0) @ centre
-        return not np.any((border - np.abs(moved)) < 0)
+        """Gate of :224-279: the image centre stays inside the image and neither axis is scaled outside [0.3, 3]."""
+        return affine_math.centre_stays_inside(t_mat, img_shape) and affine_math.scales_plausible(t_mat)
 
     def get_dog_sigmas(self, pyr_factor: int) -> Tuple[int, int]:
         if pyr_factor > 16:

@@ -40,8 +40,24 @@
 /* Host threads for the row-parallel loops below (image rows, NMI chunks, Farneback windows are independent, so the
  * results do not depend on this number).  Default 1. */
 static int g_threads = 1;
-void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+/* The row loops stop scaling long before the window fan-out does (measured on a 2 x 64-core EPYC: a 4096^2 dog()
+ * takes 0.07 s on 16-64 threads and 1 s on 256), so they use at most ORC_ROW_THREADS_MAX threads. */
+#define ORC_ROW_THREADS_MAX 32
+static int g_row_threads = 1;
+void orc_set_threads(int n)
+{
+    g_threads = n < 1 ? 1 : n;
+    g_row_threads = g_threads < ORC_ROW_THREADS_MAX ? g_threads : ORC_ROW_THREADS_MAX;
+}
 int orc_get_threads(void) { return g_threads; }
+
+/* ISA clones of the hot loops (resolved at load time, so the library runs on any x86-64): wider vectors only --
+ * -ffp-contract=off holds for every clone, each element still sees the same IEEE operations in the same order. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define ORC_CLONES __attribute__((target_clones("default", "avx2", "avx512f")))
+#else
+#define ORC_CLONES
+#endif
 
 #define ORC_U8 0
 #define ORC_U16 1
@@ -183,6 +199,7 @@ int orc_farneback_prepare_gaussian(int n, double sigma, float* g, float* xg, flo
 static void preblur3(const float* src, float* dst, int h, int w, float* tmp)
 {
     const float k0 = 0.5f, k1 = 0.25f;
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (int y = 0; y < h; y++) {
         const float* s = src + (size_t)y * w;
         float* t = tmp + (size_t)y * w;
@@ -191,6 +208,7 @@ static void preblur3(const float* src, float* dst, int h, int w, float* tmp)
             t[x] = s[x] * k0 + (a + b) * k1;
         }
     }
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (int y = 0; y < h; y++) {
         const float* t0 = tmp + (size_t)reflect101(y - 1, h) * w;
         const float* t1 = tmp + (size_t)y * w;
@@ -203,19 +221,25 @@ static void preblur3(const float* src, float* dst, int h, int w, float* tmp)
 /* Polynomial expansion -> R, 5 floats per pixel interleaved.  A.1 step 2. */
 static int poly_exp(const float* src, float* dst, int h, int w, int n, double sigma)
 {
-    int k, x, y;
     float* kbuf = (float*)malloc(sizeof(float) * (n * 6 + 3));
-    float* rowbuf = (float*)malloc(sizeof(float) * (size_t)(w + n * 2) * 3);
+    const size_t rowlen = (size_t)(w + n * 2) * 3;
+    float* rowbuf = (float*)malloc(sizeof(float) * rowlen * g_row_threads);
     if (!kbuf || !rowbuf) { free(kbuf); free(rowbuf); return ORC_ENOMEM; }
     float* g = kbuf + n;
     float* xg = g + n * 2 + 1;
     float* xxg = xg + n * 2 + 1;
-    float* row = rowbuf + n * 3;
     double ig11, ig03, ig33, ig55;
     int rc = orc_farneback_prepare_gaussian(n, sigma, g, xg, xxg, &ig11, &ig03, &ig33, &ig55);
     if (rc) { free(kbuf); free(rowbuf); return rc; }
 
-    for (y = 0; y < h; y++) {
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
+    for (int y = 0; y < h; y++) {
+        int k, x;
+#ifdef _OPENMP
+        float* row = rowbuf + rowlen * omp_get_thread_num() + n * 3;
+#else
+        float* row = rowbuf + n * 3;
+#endif
         float g0 = g[0], g1, g2;
         const float* srow0 = src + (size_t)y * w;
         const float* srow1;
@@ -276,6 +300,7 @@ static void update_matrices(const float* R0a, const float* R1, const float* flow
     enum { BORDER = 5 };
     static const float border[BORDER] = { 0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f };
     const size_t step1 = (size_t)w * 5;
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (int y = y0; y < y1; y++) {
         const float* flow = flowa + (size_t)y * w * 2;
         const float* R0 = R0a + (size_t)y * w * 5;
@@ -343,53 +368,82 @@ void orc_farneback_window_kernel(int winsize, float* kernel /* m+1 */)
 /* A.1 step 4: separable window blur of M (replicate borders) + 2x2 solve in
  * double.  Two-phase form (blur all rows, then optionally rebuild M), which is
  * exactly equivalent to OpenCV's lagging row-stripe update. */
+/* One line of the window blur: acc[x] = c[x]*k0; acc[x] = (a_i[x] + b_i[x])*k_i + acc[x] for i = 1..m, where a_i / b_i are
+ * the lines i steps after / before the centre line (rows for the vertical pass, pixels of the padded vsum row for the
+ * horizontal one).  The tap loop is the outer one so that the inner loop runs over contiguous memory; per element the
+ * operations and their order are those of the per-pixel loop. */
+ORC_CLONES static void blur_line(const float* const* after, const float* const* before, const float* centre,
+                                 const float* kernel, int m, float* acc, int n, int fused)
+{
+    const float k0 = kernel[0];
+    for (int x = 0; x < n; x++) acc[x] = centre[x] * k0;
+    for (int i = 1; i <= m; i++) {
+        const float* a = after[i];
+        const float* b = before[i];
+        const float k = kernel[i];
+        if (fused) {
+            for (int x = 0; x < n; x++) acc[x] = fmaf(a[x] + b[x], k, acc[x]);
+        } else {
+            for (int x = 0; x < n; x++) {
+                float t = (a[x] + b[x]) * k;
+                acc[x] = t + acc[x];
+            }
+        }
+    }
+}
+
 static int update_flow_gaussian(const float* R0, const float* R1, float* flow, float* M,
                                 int h, int w, int winsize, int update, int fused)
 {
     const int m = winsize / 2;
     float* kernel = (float*)malloc(sizeof(float) * (m + 1));
-    float* vsumbuf = (float*)malloc(sizeof(float) * ((size_t)(w + m * 2 + 2) * 5));
-    float* hsum = (float*)malloc(sizeof(float) * (size_t)w * 5);
-    const float** srow = (const float**)malloc(sizeof(float*) * (m * 2 + 1));
-    if (!kernel || !vsumbuf || !hsum || !srow) {
-        free(kernel); free(vsumbuf); free(hsum); free((void*)srow);
-        return ORC_ENOMEM;
-    }
-    float* vsum = vsumbuf + (m + 1) * 5;
+    if (!kernel) return ORC_ENOMEM;
     orc_farneback_window_kernel(winsize, kernel);
-
-    for (int y = 0; y < h; y++) {
-        for (int i = 0; i <= m; i++) {
-            srow[m - i] = M + (size_t)(y - i > 0 ? y - i : 0) * w * 5;
-            srow[m + i] = M + (size_t)(y + i < h - 1 ? y + i : h - 1) * w * 5;
+    int rc_all = ORC_OK;
+    /* rows are independent: M is only read here (it is rebuilt after the loop).  Inside orc_farneback_batch this
+     * region is nested and therefore runs on the calling thread alone. */
+#pragma omp parallel num_threads(g_row_threads)
+    {
+        float* vsumbuf = (float*)malloc(sizeof(float) * ((size_t)(w + m * 2 + 2) * 5));
+        float* hsum = (float*)malloc(sizeof(float) * (size_t)w * 5);
+        const float** srow = (const float**)malloc(sizeof(float*) * (m * 2 + 1) * 2);
+        if (!vsumbuf || !hsum || !srow) {
+#pragma omp critical
+            rc_all = ORC_ENOMEM;
+        } else {
+            float* vsum = vsumbuf + (m + 1) * 5;
+            const float** hrow = srow + (m * 2 + 1);
+#pragma omp for schedule(static)
+            for (int y = 0; y < h; y++) {
+                for (int i = 0; i <= m; i++) {
+                    srow[m - i] = M + (size_t)(y - i > 0 ? y - i : 0) * w * 5;
+                    srow[m + i] = M + (size_t)(y + i < h - 1 ? y + i : h - 1) * w * 5;
+                }
+                /* s0 = srow[m][x]*k0; s0 = (srow[m+i][x] + srow[m-i][x])*k_i + s0 */
+                for (int i = 0; i <= m; i++) hrow[i] = srow[m - i];
+                blur_line(srow + m, hrow, srow[m], kernel, m, vsum, w * 5, fused);
+                for (int x = 0; x < m * 5; x++) { /* replicate the first/last pixel */
+                    vsum[-1 - x] = vsum[4 - x % 5];
+                    vsum[w * 5 + x] = vsum[w * 5 - 5 + x % 5];
+                }
+                /* sum = vsum[x]*k0; sum = (vsum[x - 5i] + vsum[x + 5i])*k_i + sum */
+                for (int i = 0; i <= m; i++) { srow[i] = vsum - i * 5; hrow[i] = vsum + i * 5; }
+                blur_line(srow, hrow, vsum, kernel, m, hsum, w * 5, fused);
+                float* f = flow + (size_t)y * w * 2;
+                for (int x = 0; x < w; x++) {
+                    double g11 = hsum[x * 5], g12 = hsum[x * 5 + 1], g22 = hsum[x * 5 + 2],
+                           h1 = hsum[x * 5 + 3], h2 = hsum[x * 5 + 4];
+                    double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    f[x * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+                    f[x * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+                }
+            }
         }
-        for (int x = 0; x < w * 5; x++) {
-            float s0 = srow[m][x] * kernel[0];
-            for (int i = 1; i <= m; i++)
-                s0 = muladd_f(srow[m + i][x] + srow[m - i][x], kernel[i], s0, fused);
-            vsum[x] = s0;
-        }
-        for (int x = 0; x < m * 5; x++) { /* replicate the first/last pixel */
-            vsum[-1 - x] = vsum[4 - x % 5];
-            vsum[w * 5 + x] = vsum[w * 5 - 5 + x % 5];
-        }
-        for (int x = 0; x < w * 5; x++) {
-            float sum = vsum[x] * kernel[0];
-            for (int i = 1; i <= m; i++)
-                sum = muladd_f(vsum[x - i * 5] + vsum[x + i * 5], kernel[i], sum, fused);
-            hsum[x] = sum;
-        }
-        float* f = flow + (size_t)y * w * 2;
-        for (int x = 0; x < w; x++) {
-            double g11 = hsum[x * 5], g12 = hsum[x * 5 + 1], g22 = hsum[x * 5 + 2],
-                   h1 = hsum[x * 5 + 3], h2 = hsum[x * 5 + 4];
-            double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            f[x * 2] = (float)((g11 * h2 - g12 * h1) * idet);
-            f[x * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
-        }
+        free(vsumbuf); free(hsum); free((void*)srow);
     }
+    free(kernel);
+    if (rc_all) return rc_all;
     if (update) update_matrices(R0, R1, flow, M, h, w, 0, h);
-    free(kernel); free(vsumbuf); free(hsum); free((void*)srow);
     return ORC_OK;
 }
 
@@ -536,7 +590,7 @@ void orc_remap_tables(float* tab_f /*1024*4*/, short* tab_i /*1024*4*/)
 
 #define REMAP_BODY(T, WT, KT, LOADW, CASTEXPR) REMAP_BODY_X(T, WT, KT, LOADW, CASTEXPR, , COORDS_FROM_MAP)
 #define REMAP_BODY_X(T, WT, KT, LOADW, CASTEXPR, ROWSETUP, COORDS)                                  \
-    _Pragma("omp parallel for schedule(static) num_threads(g_threads)")                         \
+    _Pragma("omp parallel for schedule(static) num_threads(g_row_threads)")                         \
     for (int y = 0; y < dh; y++) {                                                              \
         T* drow = (T*)dst + (size_t)y * dw * cn;                                                \
         ROWSETUP                                                                                \
@@ -650,9 +704,9 @@ int orc_pyr_down(const void* src, int dtype, int h, int w, void* dst)
     int dh = (h + 1) / 2, dw = (w + 1) / 2;
     if (dtype == ORC_F32) {
         const float* s = (const float*)src;
-        float* rows_all = (float*)malloc(sizeof(float) * (size_t)dw * 5 * g_threads);
+        float* rows_all = (float*)malloc(sizeof(float) * (size_t)dw * 5 * g_row_threads);
         if (!rows_all) return ORC_ENOMEM;
-#pragma omp parallel for schedule(static) num_threads(g_threads)
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
         for (int y = 0; y < dh; y++) {
 #ifdef _OPENMP
             float* rows = rows_all + (size_t)omp_get_thread_num() * dw * 5;
@@ -679,9 +733,9 @@ int orc_pyr_down(const void* src, int dtype, int h, int w, void* dst)
         return ORC_OK;
     }
     if (dtype != ORC_U8 && dtype != ORC_U16) return ORC_EINVAL;
-    int* rows_all = (int*)malloc(sizeof(int) * (size_t)dw * 5 * g_threads);
+    int* rows_all = (int*)malloc(sizeof(int) * (size_t)dw * 5 * g_row_threads);
     if (!rows_all) return ORC_ENOMEM;
-#pragma omp parallel for schedule(static) num_threads(g_threads)
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (int y = 0; y < dh; y++) {
 #ifdef _OPENMP
         int* rows = rows_all + (size_t)omp_get_thread_num() * dw * 5;
@@ -718,11 +772,11 @@ int orc_pyr_up_f32(const float* src, int cn, int h, int w, float* dst, int dh, i
     if (h <= 0 || w <= 0 || cn < 1) return ORC_EINVAL;
     if (abs(dw - w * 2) != dw % 2 || abs(dh - h * 2) != dh % 2) return ORC_EINVAL;
     int bufw = (dw + 1 > 2 * w ? dw + 1 : 2 * w) * cn;
-    float* buf_all = (float*)malloc(sizeof(float) * (size_t)bufw * 3 * g_threads);
+    float* buf_all = (float*)malloc(sizeof(float) * (size_t)bufw * 3 * g_row_threads);
     if (!buf_all) return ORC_ENOMEM;
     /* horizontal pass of source row sy into `row` (2w columns, +1 if dw > 2w); source rows are independent
      * (row y writes destination rows 2y and min(2y+1, dh-1); for the last y both may coincide, same thread) */
-#pragma omp parallel for schedule(static) num_threads(g_threads)
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (int y = 0; y < h; y++) {
 #ifdef _OPENMP
         float* buf = buf_all + (size_t)omp_get_thread_num() * bufw * 3;
@@ -785,7 +839,7 @@ int orc_minmax(const void* src, int dtype, size_t n, double* mn, double* mx)
 {
     if (n == 0) return ORC_EINVAL;
     double lo = load_as_f32(src, dtype, 0), hi = lo;
-#pragma omp parallel for schedule(static) num_threads(g_threads) reduction(min : lo) reduction(max : hi)
+#pragma omp parallel for schedule(static) num_threads(g_row_threads) reduction(min : lo) reduction(max : hi)
     for (size_t i = 1; i < n; i++) {
         double v = load_as_f32(src, dtype, i);
         if (v < lo) lo = v;
@@ -806,7 +860,7 @@ int orc_normalize_minmax_to_f32(const void* src, int dtype, size_t n, double alp
     scale = (float)scale;
     double shift = (float)dmin - (float)(smin * scale);
     float a = (float)scale, b = (float)shift;
-#pragma omp parallel for schedule(static) num_threads(g_threads)
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (size_t i = 0; i < n; i++) {
         float v = load_as_f32(src, dtype, i);
         float p = v * a;
@@ -824,7 +878,7 @@ int orc_normalize_minmax_f32_to_u8(const float* src, size_t n, uint8_t* dst)
     double scale = 255. * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
     double shift = 0. - smin * scale;
     float a = (float)scale, b = (float)shift;
-#pragma omp parallel for schedule(static) num_threads(g_threads)
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (size_t i = 0; i < n; i++) {
         float p = src[i] * a;
         float v = p + b;
@@ -860,6 +914,22 @@ void orc_gaussian_kernel(int ksize, double sigma, float* k)
     free(v);
 }
 
+/* t[x] = t[x] + k*p[x]   and   d[x] = d[x] + k*(a[x] + b[x]): the line updates of the two GaussianBlur passes */
+ORC_CLONES static void gb_axpy(float* t, const float* p, float k, int n)
+{
+    for (int x = 0; x < n; x++) {
+        float v = k * p[x];
+        t[x] = t[x] + v;
+    }
+}
+ORC_CLONES static void gb_axpy2(float* d, const float* a, const float* b, float k, int n)
+{
+    for (int x = 0; x < n; x++) {
+        float v = k * (a[x] + b[x]);
+        d[x] = d[x] + v;
+    }
+}
+
 /* GaussianBlur(f32, (ksize,ksize), sigma), BORDER_REFLECT_101.  Row filter
  * (plain left-to-right accumulation) then symmetric column filter. */
 int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigma, float* dst)
@@ -874,9 +944,9 @@ int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigm
      * once into a reflect-101 padded buffer and the tap loop is the outer one, so that the inner loop runs over x
      * on contiguous memory: per output pixel the operations and their order are unchanged. */
     const int pw = w + 2 * r;
-    float* pad_all = (float*)malloc(sizeof(float) * (size_t)pw * g_threads);
+    float* pad_all = (float*)malloc(sizeof(float) * (size_t)pw * g_row_threads);
     if (!pad_all) { free(k); free(tmp); return ORC_ENOMEM; }
-#pragma omp parallel for schedule(static) num_threads(g_threads)
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (int y = 0; y < h; y++) {
 #ifdef _OPENMP
         float* pad = pad_all + (size_t)omp_get_thread_num() * pw;
@@ -888,17 +958,10 @@ int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigm
         for (int i = 0; i < pw; i++) pad[i] = s[reflect101(i - r, w)];
         const float k0 = k[0];
         for (int x = 0; x < w; x++) t[x] = k0 * pad[x];
-        for (int j = 1; j < ksize; j++) {
-            const float kj = k[j];
-            const float* pj = pad + j;
-            for (int x = 0; x < w; x++) {
-                float p = kj * pj[x];
-                t[x] = t[x] + p;
-            }
-        }
+        for (int j = 1; j < ksize; j++) gb_axpy(t, pad + j, k[j], w);
     }
     free(pad_all);
-#pragma omp parallel for schedule(static) num_threads(g_threads)
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (int y = 0; y < h; y++) {
         float* d = dst + (size_t)y * w;
         const float* c = tmp + (size_t)y * w;
@@ -906,11 +969,7 @@ int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigm
         for (int j = 1; j <= r; j++) {
             const float* a = tmp + (size_t)reflect101(y + j, h) * w;
             const float* b = tmp + (size_t)reflect101(y - j, h) * w;
-            float kj = k[r + j];
-            for (int x = 0; x < w; x++) {
-                float p = kj * (a[x] + b[x]);
-                d[x] = d[x] + p;
-            }
+            gb_axpy2(d, a, b, k[r + j], w);
         }
     }
     free(k); free(tmp);
@@ -934,7 +993,7 @@ int orc_dog_u8(const void* src, int dtype, int h, int w, int low_sigma, int high
     if (rc) goto done;
     rc = orc_gaussian_blur_f32(fimg, h, w, ksize, high_sigma, hs);
     if (rc) goto done;
-#pragma omp parallel for schedule(static) num_threads(g_threads)
+#pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (size_t i = 0; i < n; i++) hs[i] = hs[i] - ls[i];
     rc = orc_normalize_minmax_f32_to_u8(hs, n, dst);
 done:

@@ -155,9 +155,13 @@ def test_feature_registrator_helpers():
     a, b = np.array([[1.0, 0, 5], [0, 1, -2]]), np.array([[0.0, -1, 0], [1, 0, 3]])
     assert np.allclose(f._multiply_transform_matrices([a, b]), (np.vstack([a, [0, 0, 1]]) @ np.vstack([b, [0, 0, 1]]))[:2])
     assert np.array_equal(f._rescale_t_mat(a, 4), np.array([[1.0, 0, 20], [0, 1, -8]]))
-    assert f._check_if_proper_scale(a) and not f._check_if_proper_scale(a * np.array([[5, 5, 1]] * 2))
-    assert not f._check_if_proper_scale(np.zeros((2, 3)))
-    assert f._check_if_inside_borders(a, (100, 100)) and not f._check_if_inside_borders(np.array([[1.0, 0, 500], [0, 1, 0]]), (100, 100))
+    from microaligner_amd.feature_reg import affine_math as am
+    assert am.scales_plausible(a) and not am.scales_plausible(a * np.array([[5, 5, 1]] * 2))
+    assert not am.scales_plausible(np.zeros((2, 3)))
+    assert am.scales_plausible(np.array([[0.0, 1.0, 0], [0.0, 2.0, 0]])) is False      # rank 1: zero area
+    assert am.axis_scales(np.array([[0.0, -2.0, 3], [2.0, 0.0, 1]])) == (2.0, 2.0)     # rotation by 90 deg x 2
+    assert am.centre_stays_inside(a, (100, 100)) and not am.centre_stays_inside(np.array([[1.0, 0, 500], [0, 1, 0]]), (100, 100))
+    assert f._check_if_valid_transform(a, (100, 100))
     with pytest.raises(ValueError):
         f.ref_img = np.zeros((3, 3, 3))
     f.num_pyr_lvl = 0

@@ -177,6 +177,22 @@ def test_merge_flows_geometries(ctx, shape, T, ov):
     assert np.array_equal(got, RO.merge_flows(f1, f2, T, ov))
 
 
+@pytest.mark.parametrize("T,ov", [(100, 15), (40, 25), (0, 0)])
+def test_merge_flows_nan_window_takes_the_general_branch(ctx, T, ov):
+    """numpy's .max() propagates NaN, `nan == 0` is False: a window holding a NaN never takes a shortcut
+    (optflow_registrator.py:38-47), even when everything else in it is <= 0."""
+    h, w = 230, 260
+    f1, f2 = rand_flow(h, w, 8, 2.0), rand_flow(h, w, 9, 2.0)
+    f1[:120, :120] = -np.abs(f1[:120, :120])   # max would be 0 through the zero padding ...
+    f1[50, 60, 1] = np.nan                      # ... but for this
+    f2[100:, 100:] = 0
+    f2[200, 220, 0] = np.nan
+    exp = RO.merge_flows(f1, f2, T, ov) if T else RO.merge_two_flows(f1, f2)
+    got = ctx.merge_flows(ctx.asdevice(f1), ctx.asdevice(f2), T, ov).numpy()
+    assert np.array_equal(got, exp, equal_nan=True)
+    assert np.array_equal(np.isnan(got), np.isnan(exp))
+
+
 def test_merge_two_flows_function(ctx):
     from microaligner_amd import merge_two_flows
     f1, f2 = rand_flow(90, 80, 6, 2.0), rand_flow(90, 80, 7, 2.0)

@@ -212,3 +212,21 @@ def test_nmi_on_dog_images_matches_sklearn():
     ref, mov = synthetic.make_pair(200, 210, 12)
     a, b = O.dog(ref, True), O.dog(mov, True)
     assert abs(O.nmi_u8(a, b) - nmi(a.ravel(), b.ravel())) < 1e-12
+
+
+def test_oracle_results_do_not_depend_on_the_thread_count():
+    """Image rows, NMI chunks and Farneback windows fan out over host threads (full-size parity tests and bench.py's
+    cpu_baseline use every core): independent units, so the bits must not change."""
+    from oracle import register_oracle as RO
+    from microaligner_amd import synthetic
+    ref, mov = synthetic.make_pair(333, 410, 17)
+    params = dict(num_pyr_lvl=1, use_full_res_img=True, use_dog=True, tile_size=150, overlap=22)
+    f1, r1 = RO.register(ref, mov, nthreads=1, **params)
+    f5, r5 = RO.register(ref, mov, nthreads=5, **params)
+    assert np.array_equal(f1, f5) and r1 == r5
+    O.set_threads(3)
+    a = O.calc_optical_flow_farneback(mov, ref, 21, 2, fused=True)
+    w3 = RO.warp(mov, f1, 150, 22)
+    O.set_threads(1)
+    assert np.array_equal(a, O.calc_optical_flow_farneback(mov, ref, 21, 2, fused=True))
+    assert np.array_equal(w3, RO.warp(mov, f1, 150, 22))
