@@ -62,6 +62,7 @@ SIGNATURES = {
     "ma_pyr_down_minmax": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ma_dog_u8_minmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "ma_warp_affine_cv": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _i, _i, _vp]),
+    "ma_knn2_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
 }
 
 _lib = None

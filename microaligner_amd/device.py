@@ -426,6 +426,24 @@ class Context:
         self._run(self.lib.ma_warp_affine_cv, img.ptr, _dt(img.dtype), h, w, mm, dh, dw, out.ptr)
         return out
 
+    def knn2(self, query, train):
+        """Exact 2-NN (L2) of every row of `query` among the rows of `train` (host arrays in, host arrays out):
+        (idx (n, 2) int64, dist (n, 2) float32) like feature_reg.sparse_cpu.knn2."""
+        q = np.ascontiguousarray(query, np.float32)
+        t = np.ascontiguousarray(train, np.float32)
+        if q.ndim != 2 or t.ndim != 2 or q.shape[1] != t.shape[1]:
+            raise ValueError("query and train must be 2-D with the same descriptor length")
+        pad = -q.shape[1] % 4
+        if pad:
+            q, t = np.pad(q, ((0, 0), (0, pad))), np.pad(t, ((0, 0), (0, pad)))
+        dq, dt = self.asdevice(q), self.asdevice(t)
+        # (the image dtypes of asdevice() do not include int32: raw buffers for the results)
+        idx, dist = self.empty((len(q), 2), np.float32), self.empty((len(q), 2), np.float32)
+        self._run(self.lib.ma_knn2_l2, dq.ptr, len(q), dt.ptr, len(t), q.shape[1], idx.ptr, dist.ptr)
+        out_i = np.empty((len(q), 2), np.int32)
+        L.check(self.lib.ma_memcpy_d2h(self.handle, out_i.ctypes.data, idx.ptr, out_i.nbytes))
+        return out_i.astype(np.int64), dist.numpy()
+
     def normalize_minmax_u8(self, arr):
         out = self.empty(arr.shape, np.uint8)
         self._run(self.lib.ma_normalize_minmax_u8, arr.ptr, _dt(arr.dtype), arr.size, out.ptr)

@@ -5,6 +5,7 @@ match_features :123-158, find_features_parallelized :161-168).  The reference ge
 RANSAC similarity fit from opencv-contrib; here they come from sparse_cpu.py (see its header for what is and is not
 the same).  Tiles are processed by a thread pool instead of dask.
 """
+import os
 from concurrent.futures import ThreadPoolExecutor
 from typing import List, Optional, Sequence
 
@@ -50,10 +51,12 @@ def find_features(img: np.ndarray, nfeatures_limit: int = 5000) -> Features:
     return features
 
 
-def match_features(img1_features: Features, img2_features: Features, verbose: bool = True) -> np.ndarray:
+def match_features(img1_features: Features, img2_features: Features, verbose: bool = True, knn=None) -> np.ndarray:
     """feature_detection.py:123-158: 2-NN of every descriptor of image 2 among those of image 1, ratio test, then
     the similarity transform that maps image-2 points onto image-1 points.  Identity when there is too little to
-    go on; None (as cv2 does) when the fit itself fails is mapped to identity as well."""
+    go on; None (as cv2 does) when the fit itself fails is mapped to identity as well.
+    knn: the 2-NN search, (query, train) -> (idx, dist); FeatureRegistrator passes the device search
+    (Context.knn2 -> ma_knn2_l2), the default is the host one (sparse_cpu.knn2)."""
     identity = np.eye(2, 3)
     if not img1_features.is_valid() or not img2_features.is_valid():
         return identity
@@ -61,7 +64,7 @@ def match_features(img1_features: Features, img2_features: Features, verbose: bo
     kp2, des2 = img2_features.keypoints, img2_features.descriptors
     if len(des1) < 2:
         return identity
-    idx, dist = knn2(des2, des1)
+    idx, dist = (knn or knn2)(des2, des1)
     good = np.nonzero(dist[:, 0] < RATIO * dist[:, 1])[0]
     if verbose:
         print("    Good matches", len(good), "/", len(des2))
@@ -73,7 +76,7 @@ def match_features(img1_features: Features, img2_features: Features, verbose: bo
     return identity if mat is None else mat
 
 
-def find_features_parallelized(tile_list: Sequence[np.ndarray], workers: int = 8) -> List[Features]:
+def find_features_parallelized(tile_list: Sequence[np.ndarray], workers: Optional[int] = None) -> List[Features]:
     """feature_detection.py:161-168: at most 1 000 000 features over all tiles, at most 5000 per tile."""
     n_tiles = len(tile_list)
     if n_tiles == 0:
@@ -81,5 +84,7 @@ def find_features_parallelized(tile_list: Sequence[np.ndarray], workers: int = 8
     limit = min(1000000 // n_tiles, 5000)
     if n_tiles == 1:
         return [find_features(tile_list[0], limit)]
+    if workers is None:   # the numpy / scipy passes of a tile release the GIL: one host thread per tile, up to 32
+        workers = min(32, os.cpu_count() or 1)
     with ThreadPoolExecutor(max_workers=min(workers, n_tiles)) as ex:
         return list(ex.map(lambda t: find_features(t, limit), tile_list))

@@ -157,7 +157,8 @@ class FeatureRegistrator:
         else:
             ref_features = find_features(self._host(self.dog(ref, self.use_dog)), self.tile_size)
         mov_features = find_features(self._host(self.dog(mov_img, self.use_dog)), self.tile_size)
-        transform_mat = register_img_pair(ref_features, mov_features, self.verbose)
+        # the exact 2-NN search over up to 45 000 x 45 000 descriptors runs on the device (ma_knn2_l2)
+        transform_mat = register_img_pair(ref_features, mov_features, self.verbose, knn=get_context().knn2)
         if np.equal(transform_mat, np.eye(2, 3)).all():
             return mov_img, np.eye(2, 3)
         return self.transform_img(mov_img, transform_mat), transform_mat

@@ -120,6 +120,29 @@ def test_warp_affine_cv_bit_exact(ctx, dtype, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nq,nt,dim", [(150, 260, 200), (1, 2, 200), (700, 64, 8), (129, 1000, 198), (3000, 5000, 200)])
+def test_device_knn2_is_the_exact_search(ctx, nq, nt, dim):
+    """ma_knn2_l2 against the brute-force definition and against the host search of the sparse stage."""
+    rng = np.random.default_rng(nq + nt)
+    q, t = rng.random((nq, dim)).astype(np.float32), rng.random((nt, dim)).astype(np.float32)
+    if nt > 10:
+        t[7] = t[3]                      # an exact duplicate: the tie goes to the lower index
+        q[0] = t[3]
+    idx, dist = ctx.knn2(q, t)
+    D = np.sqrt(((q[:, None, :].astype(np.float64) - t[None].astype(np.float64)) ** 2).sum(-1)) if nq * nt < 2e5 else None
+    if D is not None:
+        o = np.argsort(D, 1, kind="stable")[:, :2]
+        assert np.array_equal(idx, o)
+        assert np.allclose(dist, np.take_along_axis(D, o, 1), rtol=1e-5, atol=1e-6)
+    hi, hd = SP.knn2(q, t)
+    assert np.array_equal(idx, hi) and np.allclose(dist, hd, rtol=1e-3, atol=1e-3)
+    if nt > 10:
+        assert list(idx[0]) == [3, 7] and dist[0, 0] == 0 and dist[0, 1] == 0
+    with pytest.raises(ValueError):
+        ctx.knn2(q, t[:1])
+
+
+@pytest.mark.gpu
 def test_feature_registrator_recovers_a_similarity_transform():
     from microaligner_amd import FeatureRegistrator, transform_img_with_tmat
     H, W = 1500, 1700
