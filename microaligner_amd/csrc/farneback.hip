@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cfloat>
+#include <cstdlib>
 
 namespace {
 
@@ -743,9 +744,17 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
         if (fast) {
             {
                 MaProfScope ps(ctx, MA_K_BLUR_V, px_v[it]);
+                static const int exp_r = getenv("MA_BV_R") ? atoi(getenv("MA_BV_R")) : BV_R;  // EXPERIMENT
+                if (exp_r == 14) {
+                    const size_t lds14 = (size_t)(BV_NW * 14 + 2 * m + 4) * 64 * sizeof(float);
+                    const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * 14 - 1) / (BV_NW * 14)) * ma_xcd_slots(nwin * 5);
+                    hipLaunchKernelGGL((fb_blur_v<14, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds14,
+                                       ctx->stream, g, m, taps, ws, nwin * 5, reach);
+                } else {
                 const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * ma_xcd_slots(nwin * 5);
                 hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_v,
                                    ctx->stream, g, m, taps, ws, nwin * 5, reach);
+                }
             }
             {
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px_h[it]);
