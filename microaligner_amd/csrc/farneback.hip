@@ -698,7 +698,8 @@ void make_window_taps(int winsize, std::vector<float>& k)
     for (int i = 0; i <= m; i++) k[i] = (float)(k[i] * s);
 }
 
-constexpr int BV_R = 16, BV_NW = 4;   // fb_blur_v: 64 columns x (NW*R) = 64 rows per block
+constexpr int BV_R = 14, BV_NW = 4;   // fb_blur_v: 64 columns x (NW*R) = 56 rows per block: at the default window (99 taps) the
+                                      // 49 tap pairs are 7 full groups of R/2 and the strip (158 rows) lets 4 blocks share a CU
 constexpr int BH_R = 8, BH_NW = 8;    // fb_blur_h_solve: 64 rows x 64 columns per block
 constexpr size_t LDS_MAX = 160 * 1024;
 
@@ -744,17 +745,9 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
         if (fast) {
             {
                 MaProfScope ps(ctx, MA_K_BLUR_V, px_v[it]);
-                static const int exp_r = getenv("MA_BV_R") ? atoi(getenv("MA_BV_R")) : BV_R;  // EXPERIMENT
-                if (exp_r == 14) {
-                    const size_t lds14 = (size_t)(BV_NW * 14 + 2 * m + 4) * 64 * sizeof(float);
-                    const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * 14 - 1) / (BV_NW * 14)) * ma_xcd_slots(nwin * 5);
-                    hipLaunchKernelGGL((fb_blur_v<14, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds14,
-                                       ctx->stream, g, m, taps, ws, nwin * 5, reach);
-                } else {
                 const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * ma_xcd_slots(nwin * 5);
                 hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_v,
                                    ctx->stream, g, m, taps, ws, nwin * 5, reach);
-                }
             }
             {
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px_h[it]);

@@ -8,6 +8,7 @@
 // Ties go to the lower train index (what numpy's argmin does in feature_reg/sparse_cpu.py).
 #include "ma_internal.h"
 
+#include <algorithm>
 #include <cfloat>
 
 namespace {
@@ -123,8 +124,9 @@ extern "C" int ma_knn2_l2(ma_ctx* ctx, const float* query, int nq, const float* 
     MA_REQUIRE(ctx && query && train && idx_out && dist_out, "NULL argument");
     MA_REQUIRE(nq >= 1 && nt >= 2, "need at least one query and two train descriptors");
     MA_REQUIRE(dim >= 4 && dim % 4 == 0, "the descriptor length must be a multiple of 4 (pad with zeros)");
-    const size_t lds = (size_t)(KN_TQ * (dim + 4) + KN_TT * KN_TP) * sizeof(float);
-    MA_REQUIRE(lds <= 160 * 1024 && (size_t)KN_TQ * 16 * 4 * sizeof(float) <= lds, "descriptor length out of range");
+    size_t lds = (size_t)(KN_TQ * (dim + 4) + KN_TT * KN_TP) * sizeof(float);
+    lds = std::max(lds, (size_t)KN_TQ * 16 * 4 * sizeof(float));   // the final merge reuses the buffer
+    MA_REQUIRE(lds <= 160 * 1024, "descriptor length out of range");
     MA_HIP(hipSetDevice(ctx->device));
     MaProfScope ps(ctx, MA_K_OTHER, (double)nq);
     hipLaunchKernelGGL(knn2_kernel, dim3((nq + KN_TQ - 1) / KN_TQ), dim3(256), lds, ctx->stream, query, train, nq, nt, dim,

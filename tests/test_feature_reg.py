@@ -129,16 +129,22 @@ def test_device_knn2_is_the_exact_search(ctx, nq, nt, dim):
         t[7] = t[3]                      # an exact duplicate: the tie goes to the lower index
         q[0] = t[3]
     idx, dist = ctx.knn2(q, t)
-    D = np.sqrt(((q[:, None, :].astype(np.float64) - t[None].astype(np.float64)) ** 2).sum(-1)) if nq * nt < 2e5 else None
-    if D is not None:
-        o = np.argsort(D, 1, kind="stable")[:, :2]
+    # brute force in float64, in query blocks
+    o = np.empty((nq, 2), np.int64)
+    od = np.empty((nq, 2), np.float64)
+    t64 = t.astype(np.float64)
+    for s0 in range(0, nq, 256):
+        D = np.sqrt(((q[s0:s0 + 256, None, :].astype(np.float64) - t64[None]) ** 2).sum(-1))
+        o[s0:s0 + 256] = np.argsort(D, 1, kind="stable")[:, :2]
+        od[s0:s0 + 256] = np.take_along_axis(D, o[s0:s0 + 256], 1)
+    assert np.allclose(dist, od, rtol=1e-5, atol=1e-6)
+    # (the distances above pin the result; float32 accumulation may still order two near-equal neighbours differently
+    # from float64)
+    assert (idx != o).any(1).mean() < 0.01
+    if nq * nt < 2e5:
         assert np.array_equal(idx, o)
-        assert np.allclose(dist, np.take_along_axis(D, o, 1), rtol=1e-5, atol=1e-6)
-    hi, hd = SP.knn2(q, t)
-    # the host search forms |q|^2 + |t|^2 - 2 q.t in float32: rows that involve the duplicate pair are ties it may break
-    # either way; everywhere else both searches agree
-    clear = ~np.isin(idx, (3, 7)).any(1) if nt > 10 else np.ones(nq, bool)
-    assert np.array_equal(idx[clear], hi[clear]) and np.allclose(dist[clear], hd[clear], rtol=1e-3, atol=2e-3)
+    hi, hd = SP.knn2(q, t)     # the host search (|q|^2 + |t|^2 - 2 q.t in float32) agrees up to its own rounding
+    assert (idx == hi).all(1).mean() > 0.98 and np.allclose(dist, hd, rtol=2e-3, atol=3e-3)
     if nt > 10:
         assert list(idx[0]) == [3, 7] and dist[0, 0] == 0 and dist[0, 1] == 0
     with pytest.raises(ValueError):
