@@ -218,6 +218,22 @@ int ma_warp_affine_cv(ma_ctx* ctx, const void* src, int dtype, int sh, int sw, c
 int ma_knn2_l2(ma_ctx* ctx, const float* query, int nq, const float* train, int nt, int dim, int* idx_out,
                float* dist_out);
 
+/* ---- dense halves of the feature stage (FeatureRegistrator), batched over nt square tiles of side P ----
+ * ma_fast_nms: FAST-9/16 corner score of the tile interiors (tile[margin:-margin, margin:-margin], as
+ * feature_detection.py:105 cuts them) kept only at strict 3x3 local maxima -- the pixels
+ * cv.FastFeatureDetector_create(threshold, True, TYPE_9_16).detect() returns, with their responses.
+ * tiles: (nt, P, P) uint8; score_out: (nt, P-2*margin, P-2*margin) int32, 0 = no keypoint. */
+int ma_fast_nms(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int margin, int threshold, int* score_out);
+/* ma_daisy_describe: DAISY descriptors (radius 21, 3 rings x 8 locations + centre, 8 orientation bins = 200 floats,
+ * no normalisation, bilinear sampling; feature_detection.py:107-110) at nkp keypoints.  tiles: (nt, P, P) uint8 or
+ * float32 (device).  weights_host[c] / radii[c]: centre-first half of the c-th incremental Gaussian kernel (host
+ * doubles, radii[c] + 1 of them); cos_sin_host: 8 x (cos, sin) of the orientation bins; offs_host: 25 x (dy, dx)
+ * sampling offsets (entry 0 = the keypoint itself, cube 0; entries 1 + 8 r + j sample cube r).  kp_tile: tile index
+ * per keypoint, kp_xy: (x, y) float64 per keypoint in tile coordinates (device).  desc_out: (nkp, 200) float32. */
+int ma_daisy_describe(ma_ctx* ctx, const void* tiles, int dtype, int nt, int P, const double* const* weights_host,
+                      const int* radii, const double* cos_sin_host, const double* offs_host, const int* kp_tile,
+                      const double* kp_xy, int nkp, float* desc_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,9 @@ SIGNATURES = {
     "ma_dog_u8_minmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "ma_warp_affine_cv": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _i, _i, _vp]),
     "ma_knn2_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "ma_fast_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ma_daisy_describe": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.POINTER(_d)), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d),
+                               _vp, _vp, _i, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,212 @@
+// Dense halves of the feature stage of FeatureRegistrator, batched over the feature tiles of one
+// pyramid level: the FAST-9/16 corner score with 3x3 non-maximum suppression and the DAISY descriptor
+// (reference: cv.FastFeatureDetector_create(threshold=1, nonmaxSuppression=True, TYPE_9_16) and
+// cv.xfeatures2d.DAISY_create(radius=21, q_radius=3, q_theta=8, q_hist=8, NRM_NONE, interpolation=True),
+// microaligner/feature_reg/feature_detection.py:88-120).  opencv-contrib is not available to this build: the kernels
+// restate microaligner_amd/feature_reg/sparse_cpu.py (numpy / scipy) operation by operation -- same float32 / float64
+// placement, same order -- so that device and host features are interchangeable; PARITY with opencv-contrib stays
+// UNPINNED exactly as for the host code (sparse_cpu.py header).  Keypoint selection (sort by response, per-tile
+// limit) stays on the host: a few thousand points per tile.
+#include "ma_internal.h"
+
+#include <cmath>
+
+namespace {
+
+// Bresenham circle of radius 3 in OpenCV's order (dx, dy)
+__constant__ int c_ring[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3}, {0, -3}, {-1, -3},
+                                  {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+// score of every pixel of the tile interior (margin cut off on all sides): max over the 16 arcs of 9 contiguous ring
+// pixels of min(v - ring) (darker arc) or min(ring - v) (brighter arc), minus 1; 0 where that maximum is <= threshold
+// or within 3 px of the interior's border
+__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ tiles, int P, int margin, int threshold,
+                                                         int* __restrict__ score)
+{
+    const int Pi = P - 2 * margin;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, t = blockIdx.z;
+    if (x >= Pi) return;
+    int s = 0;
+    if (x >= 3 && x < Pi - 3 && y >= 3 && y < Pi - 3) {
+        const uint8_t* img = tiles + (size_t)t * P * P + (size_t)(y + margin) * P + (x + margin);
+        const int v = img[0];
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = v - (int)img[c_ring[k][1] * P + c_ring[k][0]];
+        int best = -512;
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            int lo = d[a], hi = d[a];
+#pragma unroll
+            for (int j = 1; j < 9; j++) { lo = min(lo, d[(a + j) & 15]); hi = max(hi, d[(a + j) & 15]); }
+            best = max(best, max(lo, -hi));
+        }
+        s = best > threshold ? best - 1 : 0;
+    }
+    score[((size_t)t * Pi + y) * Pi + x] = s;
+}
+
+// keeps a score only where it is strictly greater than its 8 neighbours (outside the interior counts as 0)
+__global__ __launch_bounds__(256) void fast_nms_kernel(const int* __restrict__ score, int Pi, int* __restrict__ out)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, t = blockIdx.z;
+    if (x >= Pi) return;
+    const int* s = score + (size_t)t * Pi * Pi;
+    const int c = s[(size_t)y * Pi + x];
+    bool ok = c > 0;
+    for (int dy = -1; dy <= 1 && ok; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+            if (!dx && !dy) continue;
+            const int yy = y + dy, xx = x + dx;
+            const int nb = (yy >= 0 && yy < Pi && xx >= 0 && xx < Pi) ? s[(size_t)yy * Pi + xx] : 0;
+            if (!(c > nb)) { ok = false; break; }
+        }
+    out[((size_t)t * Pi + y) * Pi + x] = ok ? c : 0;
+}
+
+// Daisy._cubes, first half: f = img / 255 (uint8) or img (float32); gy, gx = np.gradient(f) in float32 (central
+// differences halved, one-sided at the border); layer o = float32(max(cos(th_o) * gx + sin(th_o) * gy, 0)) with the
+// products and the sum in float64 (numpy promotes: the cosines are float64 scalars).
+template <typename T>
+__global__ __launch_bounds__(256) void daisy_layers_kernel(const T* __restrict__ tiles, int P, const double* __restrict__ cs,
+                                                           float* __restrict__ layers)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, t = blockIdx.z;
+    if (x >= P) return;
+    const T* img = tiles + (size_t)t * P * P;
+    auto f = [&](int yy, int xx) -> float {
+        const float v = (float)img[(size_t)yy * P + xx];
+        return sizeof(T) == 1 ? v / 255.0f : v;
+    };
+    float gx, gy;
+    if (P == 1) { gx = gy = 0.f; }
+    else {
+        gx = x == 0 ? f(y, 1) - f(y, 0) : (x == P - 1 ? f(y, P - 1) - f(y, P - 2) : (f(y, x + 1) - f(y, x - 1)) / 2.0f);
+        gy = y == 0 ? f(1, x) - f(0, x) : (y == P - 1 ? f(P - 1, x) - f(P - 2, x) : (f(y + 1, x) - f(y - 1, x)) / 2.0f);
+    }
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        const double v = __dadd_rn(__dmul_rn(cs[2 * o], (double)gx), __dmul_rn(cs[2 * o + 1], (double)gy));
+        layers[(((size_t)t * 8 + o) * P + y) * P + x] = (float)(v >= 0.0 ? v : 0.0);   // np.maximum(v, 0) keeps -0.0
+    }
+}
+
+// scipy.ndimage.correlate1d(mode="nearest") with a symmetric kernel along one axis of a stack of planes: float32 in
+// and out, float64 accumulation  acc = x[0]*w[0];  acc += (x[-j] + x[+j]) * w[j]  from the outermost tap inwards.
+// w[0..r]: centre first.
+template <bool ALONG_X>
+__global__ __launch_bounds__(256) void smooth_axis_kernel(const float* __restrict__ src, int P, const double* __restrict__ w,
+                                                          int r, float* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= P) return;
+    const float* s = src + (size_t)blockIdx.z * P * P;
+    auto at = [&](int d) -> double {
+        if (ALONG_X) return (double)s[(size_t)y * P + d_clamp(x + d, 0, P - 1)];
+        return (double)s[(size_t)d_clamp(y + d, 0, P - 1) * P + x];
+    };
+    double acc = __dmul_rn(at(0), w[0]);
+    for (int j = r; j >= 1; j--) acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(at(-j), at(j)), w[j]));
+    dst[(size_t)blockIdx.z * P * P + (size_t)y * P + x] = (float)acc;
+}
+
+// Daisy.compute: one thread per (keypoint, histogram location); 25 locations x 8 orientation bins = 200 floats.
+// Location 0 samples cube 0 at the keypoint, location 1 + 8 r + j samples cube r at the keypoint + offs[1 + 8 r + j]
+// (float64 offsets computed by the host with numpy); bilinear weights and the blend in float32, left to right.
+__global__ __launch_bounds__(256) void daisy_sample_kernel(const float* __restrict__ cubes, size_t cube_stride, int P,
+                                                           const int* __restrict__ kp_tile, const double* __restrict__ kp_xy,
+                                                           const double* __restrict__ offs, int nkp, float* __restrict__ desc)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nkp * 25) return;
+    const int k = e / 25, loc = e - k * 25;
+    const int cube = loc == 0 ? 0 : (loc - 1) / 8;
+    double ys = kp_xy[2 * k + 1] + offs[2 * loc], xs = kp_xy[2 * k] + offs[2 * loc + 1];
+    ys = fmin(fmax(ys, 0.0), (double)P - 1.0);
+    xs = fmin(fmax(xs, 0.0), (double)P - 1.0);
+    long long y0 = (long long)floor(ys), x0 = (long long)floor(xs);
+    if (P > 1) { y0 = y0 < P - 2 ? y0 : P - 2; x0 = x0 < P - 2 ? x0 : P - 2; } else { y0 = x0 = 0; }
+    const float fy = (float)(ys - (double)y0), fx = (float)(xs - (double)x0);
+    const long long y1 = y0 + 1 < P - 1 ? y0 + 1 : P - 1, x1 = x0 + 1 < P - 1 ? x0 + 1 : P - 1;
+    const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
+    const float* base = cubes + cube * cube_stride + (size_t)kp_tile[k] * 8 * P * P;
+    float* out = desc + (size_t)k * 200 + loc * 8;
+#pragma unroll
+    for (int o = 0; o < 8; o++) {
+        const float* pl = base + (size_t)o * P * P;
+        out[o] = pl[y0 * P + x0] * w00 + pl[y0 * P + x1] * w01 + pl[y1 * P + x0] * w10 + pl[y1 * P + x1] * w11;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int ma_fast_nms(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int margin, int threshold, int* score_out)
+{
+    MA_REQUIRE(ctx && tiles && score_out, "NULL argument");
+    MA_REQUIRE(nt >= 1 && nt <= 65535 && margin >= 0 && P - 2 * margin >= 1 && P - 2 * margin <= 65535, "bad tile geometry");
+    MA_HIP(hipSetDevice(ctx->device));
+    const int Pi = P - 2 * margin;
+    MA_TRY(ma_ws_reserve(ctx, (size_t)nt * Pi * Pi * sizeof(int)));
+    MaProfScope ps(ctx, MA_K_OTHER, (double)nt * Pi * Pi);
+    const dim3 grid((Pi + 255) / 256, Pi, nt);
+    hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, ctx->stream, tiles, P, margin, threshold, (int*)ctx->ws);
+    hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, ctx->stream, (const int*)ctx->ws, Pi, score_out);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+int ma_daisy_describe(ma_ctx* ctx, const void* tiles, int dtype, int nt, int P, const double* const* weights_host,
+                      const int* radii, const double* cos_sin_host, const double* offs_host, const int* kp_tile,
+                      const double* kp_xy, int nkp, float* desc_out)
+{
+    MA_REQUIRE(ctx && tiles && weights_host && radii && cos_sin_host && offs_host && kp_tile && kp_xy && desc_out, "NULL argument");
+    MA_REQUIRE(dtype == MA_U8 || dtype == MA_F32, "tiles must be uint8 or float32");
+    MA_REQUIRE(nt >= 1 && nt * 8 <= 65535 && P >= 1 && P <= 65535 && nkp >= 1, "bad tile geometry");
+    MA_REQUIRE(radii[0] >= 0 && radii[1] >= 0 && radii[2] >= 0 && radii[0] + radii[1] + radii[2] < 4096, "bad radii");
+    MA_HIP(hipSetDevice(ctx->device));
+    // small tables: 8 (cos, sin) pairs, 25 (dy, dx) offsets, three centre-first half kernels
+    const size_t ntab = 16 + 50 + (size_t)(radii[0] + radii[1] + radii[2] + 3);
+    MA_TRY(ma_dconst_reserve(ctx, ntab * sizeof(double)));
+    std::vector<double> tab(ntab);
+    for (int i = 0; i < 16; i++) tab[i] = cos_sin_host[i];
+    for (int i = 0; i < 50; i++) tab[16 + i] = offs_host[i];
+    size_t woff[3], o = 66;
+    for (int c = 0; c < 3; c++) {
+        woff[c] = o;
+        for (int j = 0; j <= radii[c]; j++) tab[o++] = weights_host[c][j];
+    }
+    double* dtab = (double*)ctx->dconst;
+    MA_HIP(hipMemcpyAsync(dtab, tab.data(), ntab * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));   // `tab` goes out of scope
+
+    // workspace: cubes 0..2 and one temporary, each nt x 8 planes of P x P float32
+    const size_t cube = (size_t)nt * 8 * P * P;
+    MA_TRY(ma_ws_reserve(ctx, 4 * cube * sizeof(float)));
+    float* cubes = (float*)ctx->ws;
+    float* tmp = cubes + 3 * cube;
+    MaProfScope ps(ctx, MA_K_OTHER, (double)nt * P * P);
+    {
+        const dim3 grid((P + 255) / 256, P, nt);
+        if (dtype == MA_U8) hipLaunchKernelGGL((daisy_layers_kernel<uint8_t>), grid, dim3(256), 0, ctx->stream, (const uint8_t*)tiles, P, dtab, tmp);
+        else hipLaunchKernelGGL((daisy_layers_kernel<float>), grid, dim3(256), 0, ctx->stream, (const float*)tiles, P, dtab, tmp);
+    }
+    const dim3 pgrid((P + 255) / 256, P, nt * 8);
+    const float* src = tmp;   // the orientation layers; smoothed successively: cube c = G(inc_c) * cube c-1
+    for (int c = 0; c < 3; c++) {
+        float* dst = cubes + c * cube;
+        // scipy filters axis 1 (y) first, then axis 2 (x), each pass rounding to float32.  The intermediate of the two
+        // passes lives in the next cube's slot (not yet written) or, for the last cube, in the layer buffer (done with)
+        float* mid = c < 2 ? cubes + (c + 1) * cube : tmp;
+        hipLaunchKernelGGL((smooth_axis_kernel<false>), pgrid, dim3(256), 0, ctx->stream, src, P, dtab + woff[c], radii[c], mid);
+        hipLaunchKernelGGL((smooth_axis_kernel<true>), pgrid, dim3(256), 0, ctx->stream, (const float*)mid, P, dtab + woff[c], radii[c], dst);
+        src = dst;
+    }
+    hipLaunchKernelGGL(daisy_sample_kernel, dim3((nkp * 25 + 255) / 256), dim3(256), 0, ctx->stream, (const float*)cubes, cube, P,
+                       kp_tile, kp_xy, dtab + 16, nkp, desc_out);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+} // extern "C"

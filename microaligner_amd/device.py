@@ -444,6 +444,46 @@ class Context:
         L.check(self.lib.ma_memcpy_d2h(self.handle, out_i.ctypes.data, idx.ptr, out_i.nbytes))
         return out_i.astype(np.int64), dist.numpy()
 
+    def _raw(self, nbytes):
+        """Untyped HBM buffer from the pool (results that are not image dtypes: int32 scores, float64 points)."""
+        return self.empty((max(int(nbytes), 1),), np.uint8)
+
+    def _upload_raw(self, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = self._raw(arr.nbytes)
+        if arr.nbytes:
+            L.check(self.lib.ma_memcpy_h2d(self.handle, buf.ptr, arr.ctypes.data, arr.nbytes))
+        return buf
+
+    def fast_nms(self, tiles, margin, threshold=1):
+        """FAST-9/16 score at the 3x3 local maxima of every tile interior: (nt, P-2m, P-2m) int32 on the host."""
+        nt, P, P2 = tiles.shape
+        if P != P2 or tiles.dtype != np.uint8:
+            raise ValueError("FAST works on square uint8 tiles (the DOG output)")
+        Pi = P - 2 * margin
+        out = self._raw(nt * Pi * Pi * 4)
+        self._run(self.lib.ma_fast_nms, tiles.ptr, nt, P, int(margin), int(threshold), out.ptr)
+        host = np.empty((nt, Pi, Pi), np.int32)
+        L.check(self.lib.ma_memcpy_d2h(self.handle, host.ctypes.data, out.ptr, host.nbytes))
+        return host
+
+    def daisy_describe(self, tiles, kp_tile, kp_xy, weights, cos_sin, offsets):
+        """DAISY descriptors at the given keypoints: (n, 200) float32 on the host (see ma_daisy_describe)."""
+        nt, P, _ = tiles.shape
+        n = len(kp_tile)
+        d_tile = self._upload_raw(np.asarray(kp_tile, np.int32))
+        d_xy = self._upload_raw(np.asarray(kp_xy, np.float64))
+        desc = self.empty((n, 200), np.float32)
+        halves = [np.ascontiguousarray(w, np.float64) for w in weights]
+        wptr = (C.POINTER(C.c_double) * 3)(*[h.ctypes.data_as(C.POINTER(C.c_double)) for h in halves])
+        radii = (C.c_int * 3)(*[len(h) - 1 for h in halves])
+        cs = np.ascontiguousarray(cos_sin, np.float64)
+        of = np.ascontiguousarray(offsets, np.float64)
+        self._run(self.lib.ma_daisy_describe, tiles.ptr, _dt(tiles.dtype), nt, P, wptr, radii,
+                  cs.ctypes.data_as(C.POINTER(C.c_double)), of.ctypes.data_as(C.POINTER(C.c_double)), d_tile.ptr, d_xy.ptr,
+                  n, desc.ptr)
+        return desc.numpy()
+
     def normalize_minmax_u8(self, arr):
         out = self.empty(arr.shape, np.uint8)
         self._run(self.lib.ma_normalize_minmax_u8, arr.ptr, _dt(arr.dtype), arr.size, out.ptr)

@@ -76,6 +76,64 @@ def match_features(img1_features: Features, img2_features: Features, verbose: bo
     return identity if mat is None else mat
 
 
+def _daisy_tables(daisy: Daisy):
+    """Host-side constants of the device DAISY (ma_daisy_describe): the centre-first halves of scipy's Gaussian
+    kernels for the three smoothing increments (truncate 3.0), the (cos, sin) of the orientation bins and the
+    sampling offsets -- the very doubles sparse_cpu.Daisy uses."""
+    from scipy.ndimage._filters import _gaussian_kernel1d
+    halves = []
+    for inc in daisy.smoothing_increments():
+        lw = int(3.0 * inc + 0.5)
+        halves.append(_gaussian_kernel1d(inc, 0, lw)[lw:])
+    th = [2.0 * np.pi * o / daisy.q_hist for o in range(daisy.q_hist)]
+    cos_sin = np.array([(np.cos(t), np.sin(t)) for t in th], np.float64)
+    return halves, cos_sin, daisy.sample_offsets()
+
+
+def find_features_device(tile_list: Sequence[np.ndarray], ctx) -> List[Features]:
+    """find_features_parallelized with the dense work on the device, all tiles of the level in one batch: the FAST
+    score map with non-maximum suppression (ma_fast_nms) and the DAISY orientation layers, their three Gaussian
+    smoothings and the descriptor sampling (ma_daisy_describe).  The host keeps what is sparse: picking the
+    strongest corners of each tile.  Same keypoints, same descriptors as find_features (tests compare them)."""
+    n_tiles = len(tile_list)
+    if n_tiles == 0:
+        return []
+    limit = min(1000000 // n_tiles, 5000)
+    tiles = np.ascontiguousarray(np.stack([np.asarray(t) for t in tile_list]))
+    if tiles.dtype != np.uint8:
+        raise ValueError("FAST works on uint8 images (the DOG output)")
+    feats = [Features() for _ in range(n_tiles)]
+    if tiles.shape[1] <= 2 * TILE_OVERLAP:
+        return feats
+    d_tiles = ctx.asdevice(tiles)
+    score = ctx.fast_nms(d_tiles, TILE_OVERLAP, threshold=1)
+    picked, kp_tile, kp_xy = {}, [], []
+    for t in range(n_tiles):
+        if tiles[t].max() == 0:
+            continue
+        ys, xs = np.nonzero(score[t])
+        if len(ys) == 0:
+            continue
+        resp = score[t][ys, xs]
+        order = np.argsort(-resp, kind="stable")[:limit]      # strongest first, row-major order among equals
+        picked[t] = (xs[order], ys[order], resp[order])
+        kp_tile.append(np.full(len(order), t, np.int32))
+        kp_xy.append(np.stack([xs[order], ys[order]], 1).astype(np.float64))
+    if not picked:
+        return feats
+    daisy = Daisy(radius=21, q_radius=3, q_theta=8, q_hist=8)
+    halves, cos_sin, offsets = _daisy_tables(daisy)
+    des = ctx.daisy_describe(d_tiles, np.concatenate(kp_tile), np.concatenate(kp_xy), halves, cos_sin, offsets)
+    pos = 0
+    for t, (xs, ys, resp) in picked.items():
+        n = len(xs)
+        if n >= 3:
+            feats[t].keypoints = [KeyPoint((float(x), float(y)), 7.0, -1.0, float(r), 0, -1) for x, y, r in zip(xs, ys, resp)]
+            feats[t].descriptors = des[pos:pos + n].copy()
+        pos += n
+    return feats
+
+
 def find_features_parallelized(tile_list: Sequence[np.ndarray], workers: Optional[int] = None) -> List[Features]:
     """feature_detection.py:161-168: at most 1 000 000 features over all tiles, at most 5000 per tile."""
     n_tiles = len(tile_list)

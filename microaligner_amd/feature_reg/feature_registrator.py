@@ -61,7 +61,7 @@ class FeatureRegistrator:
     def calc_ref_img_features(self):
         """:70-76: pyramid of the reference image and the features of every level."""
         self._ref_img_pyr, self._factors = self._generate_img_pyr(self._ref_img)
-        self._ref_pyr_features = [find_features(self._host(self.dog(lvl, self.use_dog)), self.tile_size)
+        self._ref_pyr_features = [find_features(self._host(self.dog(lvl, self.use_dog)), self.tile_size, get_context())
                                   for lvl in self._ref_img_pyr]
 
     def register(self, reuse_ref_img: bool = False) -> np.ndarray:
@@ -155,8 +155,8 @@ class FeatureRegistrator:
         if isinstance(ref, Features):
             ref_features = ref
         else:
-            ref_features = find_features(self._host(self.dog(ref, self.use_dog)), self.tile_size)
-        mov_features = find_features(self._host(self.dog(mov_img, self.use_dog)), self.tile_size)
+            ref_features = find_features(self._host(self.dog(ref, self.use_dog)), self.tile_size, get_context())
+        mov_features = find_features(self._host(self.dog(mov_img, self.use_dog)), self.tile_size, get_context())
         # the exact 2-NN search over up to 45 000 x 45 000 descriptors runs on the device (ma_knn2_l2)
         transform_mat = register_img_pair(ref_features, mov_features, self.verbose, knn=get_context().knn2)
         if np.equal(transform_mat, np.eye(2, 3)).all():

@@ -91,6 +91,25 @@ class Daisy:
     def __init__(self, radius=21, q_radius=3, q_theta=8, q_hist=8):
         self.radius, self.q_radius, self.q_theta, self.q_hist = radius, q_radius, q_theta, q_hist
 
+    def smoothing_increments(self) -> List[float]:
+        """Sigma of the Gaussian that takes cube r-1 to cube r (cube -1 = the orientation layers)."""
+        sigmas = [self.radius * (r + 1) / (2.0 * self.q_radius) for r in range(self.q_radius)]
+        prev, incs = 0.0, []
+        for s in sigmas:
+            incs.append(float(np.sqrt(s * s - prev * prev)))
+            prev = s
+        return incs
+
+    def sample_offsets(self) -> np.ndarray:
+        """(dy, dx) of the 1 + q_radius * q_theta histogram locations relative to the keypoint, in compute()'s order."""
+        offs = [(0.0, 0.0)]
+        for r in range(self.q_radius):
+            rad = self.radius * (r + 1) / self.q_radius
+            for j in range(self.q_theta):
+                ang = 2.0 * np.pi * j / self.q_theta
+                offs.append((rad * np.sin(ang), rad * np.cos(ang)))
+        return np.array(offs, np.float64)
+
     def _cubes(self, img: np.ndarray) -> List[np.ndarray]:
         from scipy.ndimage import gaussian_filter
         f = img.astype(np.float32) / (255.0 if img.dtype == np.uint8 else 1.0)

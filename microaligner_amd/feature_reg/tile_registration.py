@@ -5,7 +5,8 @@ from typing import List
 import numpy as np
 
 from ..shared_modules.tiling import TileGrid
-from .feature_detection import TILE_OVERLAP, Features, find_features_parallelized, match_features
+from .feature_detection import (TILE_OVERLAP, Features, find_features_device, find_features_parallelized,
+                                match_features)
 from .sparse_cpu import KeyPoint
 
 
@@ -43,10 +44,12 @@ def combine_features(feature_list: List[Features], x_ntiles: int, y_ntiles: int,
     return combined
 
 
-def find_features(img: np.ndarray, tile_size: int) -> Features:
+def find_features(img: np.ndarray, tile_size: int, ctx=None) -> Features:
+    """Features of all tiles of `img` in image coordinates.  With a device context the dense work (FAST score map,
+    DAISY layers / smoothing / sampling) runs there for all tiles at once, otherwise on a host thread per tile."""
     tiles, info = split_image_into_tiles(img, tile_size)
     tile_h, tile_w = info["tile_shape"]
-    per_tile = find_features_parallelized(tiles)
+    per_tile = find_features_device(tiles, ctx) if ctx is not None else find_features_parallelized(tiles)
     return combine_features(per_tile, info["ntiles"]["x"], info["ntiles"]["y"], tile_w, tile_h)
 
 

@@ -152,6 +152,26 @@ def test_device_knn2_is_the_exact_search(ctx, nq, nt, dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,tile,seed", [((450, 620), 300, 3), ((700, 700), 1000, 4), ((1300, 1100), 400, 5)])
+def test_device_features_equal_the_host_features(ctx, shape, tile, seed):
+    """ma_fast_nms + ma_daisy_describe (all tiles of a level in one batch) against the numpy / scipy code of the
+    sparse stage tile by tile: same keypoints in the same order, same descriptors."""
+    img = O.dog(synthetic.make_cells(*shape, seed=seed), True)
+    host = TR.find_features(img, tile)
+    dev = TR.find_features(img, tile, ctx)
+    assert host.is_valid() and dev.is_valid() and len(dev.keypoints) == len(host.keypoints)
+    assert [(k.pt, k.response) for k in dev.keypoints] == [(k.pt, k.response) for k in host.keypoints]
+    assert dev.descriptors.shape == host.descriptors.shape and dev.descriptors.dtype == np.float32
+    diff = np.abs(dev.descriptors - host.descriptors)
+    print("descriptor max |d|", diff.max(), "differing", int((diff > 0).sum()), "/", diff.size)
+    assert diff.max() <= 1e-6
+    # an all-zero tile and a featureless image
+    assert not TR.find_features(np.zeros((300, 300), np.uint8), 200, ctx).is_valid()
+    with pytest.raises(ValueError):
+        TR.find_features(img.astype(np.uint16), tile, ctx)
+
+
+@pytest.mark.gpu
 def test_feature_registrator_recovers_a_similarity_transform():
     from microaligner_amd import FeatureRegistrator, transform_img_with_tmat
     H, W = 1500, 1700
