@@ -214,7 +214,8 @@ int ma_warp_affine_cv(ma_ctx* ctx, const void* src, int dtype, int sh, int sw, c
  * Replaces cv2.FlannBasedMatcher().knnMatch(query, train, k=2) (feature_reg/feature_detection.py:137-141) with the
  * EXACT search: for every query row the two train rows at the smallest L2 distance, ties to the lower index.
  * query: (nq, dim) float32, train: (nt, dim) float32, dim a multiple of 4 (pad with zeros), nt >= 2; idx_out:
- * (nq, 2) int32, dist_out: (nq, 2) float32 (Euclidean distance, not squared).  All device pointers. */
+ * (nq, 2) int32, dist_out: (nq, 2) float32 SQUARED distances, accumulated in float32 over ascending dimension
+ * (d2 = d2 + diff*diff, two roundings).  All device pointers. */
 int ma_knn2_l2(ma_ctx* ctx, const float* query, int nq, const float* train, int nt, int dim, int* idx_out,
                float* dist_out);
 

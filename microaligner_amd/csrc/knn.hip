@@ -4,7 +4,7 @@
 // iteration -- an approximate kd-tree search in OpenCV C++; here it is the exact search, one pass over the distance
 // matrix that is never stored: a block owns 64 queries (resident in LDS), streams the train set through LDS in
 // 64-row tiles and 32-dimension chunks, every thread accumulates a 4 x 4 patch of squared distances
-// (d2 += (q - t)^2, ascending dimension, fused multiply-add) and keeps the two smallest per query.
+// (d2 = d2 + (q - t)^2 in float32, ascending dimension, product and sum rounded separately) and keeps the two smallest per query.
 // Ties go to the lower train index (what numpy's argmin does in feature_reg/sparse_cpu.py).
 #include "ma_internal.h"
 
@@ -71,11 +71,13 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
                 for (int r = 0; r < 4; r++)
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
+                        // d2 = d2 + d*d, product and sum rounded separately (the file is built with -ffp-contract=off):
+                        // the definition sparse_cpu.knn2_sequential restates with numpy, bit for bit
                         float d;
-                        d = qv[r].x - tv[c].x; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
-                        d = qv[r].y - tv[c].y; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
-                        d = qv[r].z - tv[c].z; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
-                        d = qv[r].w - tv[c].w; acc[r][c] = __builtin_fmaf(d, d, acc[r][c]);
+                        d = qv[r].x - tv[c].x; acc[r][c] = acc[r][c] + d * d;
+                        d = qv[r].y - tv[c].y; acc[r][c] = acc[r][c] + d * d;
+                        d = qv[r].z - tv[c].z; acc[r][c] = acc[r][c] + d * d;
+                        d = qv[r].w - tv[c].w; acc[r][c] = acc[r][c] + d * d;
                     }
             }
         }
@@ -111,8 +113,8 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
         }
         idx[(size_t)(q0 + tid) * 2] = i0;
         idx[(size_t)(q0 + tid) * 2 + 1] = i1;
-        dist[(size_t)(q0 + tid) * 2] = sqrtf(d0);
-        dist[(size_t)(q0 + tid) * 2 + 1] = sqrtf(d1);
+        dist[(size_t)(q0 + tid) * 2] = d0;      // squared; the caller takes the root
+        dist[(size_t)(q0 + tid) * 2 + 1] = d1;
     }
 }
 

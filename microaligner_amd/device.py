@@ -442,7 +442,7 @@ class Context:
         self._run(self.lib.ma_knn2_l2, dq.ptr, len(q), dt.ptr, len(t), q.shape[1], idx.ptr, dist.ptr)
         out_i = np.empty((len(q), 2), np.int32)
         L.check(self.lib.ma_memcpy_d2h(self.handle, out_i.ctypes.data, idx.ptr, out_i.nbytes))
-        return out_i.astype(np.int64), dist.numpy()
+        return out_i.astype(np.int64), np.sqrt(dist.numpy())   # the kernel returns squared distances
 
     def _raw(self, nbytes):
         """Untyped HBM buffer from the pool (results that are not image dtypes: int32 scores, float64 points)."""

@@ -174,6 +174,33 @@ def knn2(query: np.ndarray, train: np.ndarray, block: int = 1024):
     return idx, dist
 
 
+def knn2_sequential(query: np.ndarray, train: np.ndarray, block: int = 256):
+    """The DEFINITION the device search (ma_knn2_l2) implements, restated with numpy: squared distance accumulated in
+    float32 over ascending dimension, d2 = d2 + diff * diff with the product and the sum rounded separately; the two
+    smallest per query, ties to the lower index; distances are the float32 roots.  Slow (one pass over the distance
+    block per dimension): for tests and for generating fixtures, not for 45 000 x 45 000 problems."""
+    q = np.ascontiguousarray(query, np.float32)
+    tt = np.ascontiguousarray(np.asarray(train, np.float32).T)      # (dim, nt): contiguous rows per dimension
+    idx = np.empty((len(q), 2), np.int64)
+    dist = np.empty((len(q), 2), np.float32)
+    for s in range(0, len(q), block):
+        qb = q[s:s + block]
+        d2 = np.zeros((len(qb), tt.shape[1]), np.float32)
+        diff = np.empty_like(d2)
+        for k in range(tt.shape[0]):
+            np.subtract(qb[:, k, None], tt[k][None, :], out=diff)
+            np.multiply(diff, diff, out=diff)
+            np.add(d2, diff, out=d2)
+        rows = np.arange(len(qb))
+        i0 = d2.argmin(1)
+        v0 = d2[rows, i0].copy()
+        d2[rows, i0] = np.inf
+        i1 = d2.argmin(1)          # among equal values argmin returns the lowest index, and i0 < i1 on exact ties
+        idx[s:s + block, 0], idx[s:s + block, 1] = i0, i1
+        dist[s:s + block, 0], dist[s:s + block, 1] = np.sqrt(v0), np.sqrt(d2[rows, i1])
+    return idx, dist
+
+
 def _blas_threads(n):
     """Caps the BLAS thread pool for the block products (hundreds of spinning threads on a many-core host are
     slower than 16 for these sizes, and pathological when the host is shared); a no-op without threadpoolctl."""

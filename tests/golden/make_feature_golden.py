@@ -81,7 +81,7 @@ def _install_sparse_standins():
     class _Matcher:
         def knnMatch(self, query, train, k=2):
             assert k == 2
-            idx, dist = SP.knn2(query, train)
+            idx, dist = SP.knn2_sequential(query, train)   # the definition the device search implements, bit for bit
             return [[_DMatch(q, int(idx[q, 0]), dist[q, 0]), _DMatch(q, int(idx[q, 1]), dist[q, 1])]
                     for q in range(len(idx))]
 

@@ -143,6 +143,9 @@ def test_device_knn2_is_the_exact_search(ctx, nq, nt, dim):
     assert (idx != o).any(1).mean() < 0.01
     if nq * nt < 2e5:
         assert np.array_equal(idx, o)
+    if nq * nt <= 3000 * 5000:
+        si, sd = SP.knn2_sequential(q, t)          # the float32 definition, restated with numpy: bit for bit
+        assert np.array_equal(idx, si) and np.array_equal(dist, sd)
     hi, hd = SP.knn2(q, t)     # the host search (|q|^2 + |t|^2 - 2 q.t in float32) agrees up to its own rounding,
     far = od[:, 0] > 0.1       # which is large for (near-)duplicates: cancellation
     assert (idx == hi).all(1).mean() > 0.98 and np.allclose(dist[far], hd[far], rtol=2e-3, atol=3e-3)
