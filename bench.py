@@ -287,6 +287,8 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the informational legs (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--lanes", type=int, default=3, help="pairs in flight for the informational multi-lane leg (0: skip)")
+    ap.add_argument("--feature-init", action="store_true",
+                    help="cfg5: FeatureRegistrator.register() supplies the affine initialisation inside the timed step")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduce plumbing only, no GPU work (CPU test of the N-rank launcher)")
     args = ap.parse_args()
@@ -345,19 +347,22 @@ def main():
     ctx = get_context()
 
     np_dtype = np.uint8 if args.dtype == "u8" else np.float32
-    ref, mov = synthetic.make_pair(H, W, seed=1 + rank, dtype=np_dtype)
-    inv_affine = None
+    inv_affine, freg = None, None
     if wl.get("affine"):
-        # mosaic tile: the moving image additionally carries a known similarity (rotation <= 0.5 deg, shift <= 20 px)
-        rng = np.random.default_rng(100 + rank)
-        ang = np.deg2rad(rng.uniform(-0.5, 0.5))
-        tx, ty = rng.uniform(-20, 20, 2)
-        c, s = np.cos(ang), np.sin(ang)
-        fwd = np.array([[c, -s, tx + (1 - c) * W / 2 + s * H / 2], [s, c, ty - s * W / 2 + (1 - c) * H / 2], [0, 0, 1]])
-        mov = ctx.warp_affine(ctx.asdevice(mov), fwd).numpy()          # misplace the tile ...
-        inv_affine = np.linalg.inv(fwd)                                # ... the initialisation undoes it
+        # mosaic tile: cell-like texture, the moving image misplaced by a known similarity (rotation <= 0.5 deg,
+        # shift <= 20 px) plus a smooth residual.  Affine initialisation: the known matrix (default; SURVEY 8d:
+        # "ground-truth matrix where opencv-contrib is absent") or, with --feature-init, FeatureRegistrator.register()
+        # inside the timed step (its sparse selection / matching glue runs on the host)
+        ref, mov, M = synthetic.make_mosaic_tile(H, W, seed=1 + rank, dtype=np_dtype)
+        inv_affine = np.vstack([M, [0, 0, 1]])        # pinv of the 3x3 of T = M^-1: what transform_img_with_tmat applies
+        if args.feature_init:
+            from microaligner_amd import FeatureRegistrator
+            freg = FeatureRegistrator()
+            freg.verbose = False
+    else:
+        ref, mov = synthetic.make_pair(H, W, seed=1 + rank, dtype=np_dtype)
     dref, dmov = ctx.asdevice(ref), ctx.asdevice(mov)
-    if not (world == 1 and not args.no_variants):
+    if not (world == 1 and not args.no_variants) and freg is None:
         del ref, mov
 
     reg = OptFlowRegistrator()
@@ -369,7 +374,12 @@ def main():
     warper.tile_size, warper.overlap = reg.tile_size, reg.overlap
 
     def step():
-        m = dmov if inv_affine is None else ctx.warp_affine(dmov, inv_affine)   # transform_img_with_tmat (utils.py:98-114)
+        if freg is not None:
+            freg.ref_img, freg.mov_img = ref, mov
+            t_mat = freg.register()
+            m = ctx.warp_affine(dmov, np.linalg.pinv(np.vstack([t_mat, [0, 0, 1]])))
+        else:
+            m = dmov if inv_affine is None else ctx.warp_affine(dmov, inv_affine)   # transform_img_with_tmat (utils.py:98-114)
         reg.ref_img, reg.mov_img = dref, m
         flow = reg.register()
         warper.image, warper.flow = m, flow
@@ -419,7 +429,8 @@ def main():
                        "pairs_per_step": world, "tile_size": reg.tile_size, "overlap": reg.overlap,
                        "num_iterations": reg.num_iterations, "muladd": "fma" if args.fused else "mul+add",
                        "levels": [[r.factor, r.accepted] for r in reg.level_reports],
-                       "devices": ndev,
+                       "devices": ndev, "affine_init": ("FeatureRegistrator" if freg is not None else
+                                                        "known matrix" if inv_affine is not None else None),
                        "parallelism": f"{world} independent pairs, one rank per pair, {min(world, ndev)} GPU(s), no collective"},
             "roofline": kernels.get(dominant),
             "roofline_polyexp": kernels.get("polyexp_m0"),
@@ -432,10 +443,11 @@ def main():
             # never the headline value)
             th = host_inclusive_leg(max(1, min(args.steps, 3)), ref, mov if inv_affine is None else
                                     ctx.warp_affine(dmov, inv_affine).numpy(), params)
+            if freg is None:
+                del ref, mov
             res["variants"]["host_inclusive"] = {"value": round(H * W / th / 1e6, 2), "unit": "Mpix/s",
                                                  "ms_per_step": round(th * 1e3, 3),
                                                  "what": "numpy in -> numpy out: H2D of ref and mov, register(), warp(), D2H of flow and warped image"}
-            del ref, mov
             # informational: the same workload with the window blur in the FMA rounding model
             # (MA_FB_MULADD_FUSED: OpenCV builds whose v_muladd is a fused multiply-add); not the headline value
             reg.muladd_fused = True

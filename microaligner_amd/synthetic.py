@@ -110,3 +110,43 @@ def make_cells(H, W, n=None, seed=1, dtype=np.uint16):
     if np.dtype(dtype) == np.uint16:
         return (img * 60000).astype(np.uint16)
     return (img * 255).astype(np.float32)
+
+
+def mosaic_tile_transform(H, W, seed):
+    """The known similarity a mosaic tile of BASELINE cfg5 is misplaced by: rotation <= 0.5 deg about the tile
+    centre, shift <= 20 px.  Returns the 2x3 matrix M with mov(p) = ref(M^-1 p) away from the border, i.e.
+    cv2.warpAffine(ref, M) -- the transform FeatureRegistrator.register() is expected to undo (it returns ~M^-1)."""
+    rng = np.random.default_rng(1000 + seed)
+    ang = np.deg2rad(rng.uniform(-0.5, 0.5))
+    tx, ty = rng.uniform(-20, 20, 2)
+    c, s = np.cos(ang), np.sin(ang)
+    cx, cy = W / 2.0, H / 2.0
+    return np.array([[c, -s, tx + cx - c * cx + s * cy], [s, c, ty + cy - s * cx - c * cy]], np.float64)
+
+
+def make_mosaic_tile(H, W, seed, dtype=np.uint16, amp=1.5):
+    """(ref, mov, M) of one mosaic tile of cfg5: cell-like reference, moving image = the reference under the known
+    similarity M (bilinear, zero border) followed by a small smooth non-linear displacement of amplitude `amp` px,
+    which is what the optical-flow stage is there to remove."""
+    from scipy.ndimage import map_coordinates
+    ref = make_cells(H, W, seed=seed, dtype=np.float32)
+    M = mosaic_tile_transform(H, W, seed)
+    inv = np.linalg.inv(np.vstack([M, [0, 0, 1]]))[:2]
+    mov = np.empty((H, W), np.float32)
+    band = 512
+
+    def rows(y0):
+        y1 = min(y0 + band, H)
+        yy = np.arange(y0, y1, dtype=np.float64)[:, None]
+        xx = np.arange(W, dtype=np.float64)[None, :]
+        xs = xx + amp * np.sin(yy / 97.0)               # smooth residual, then the similarity
+        ys = yy + amp * np.cos(xx / 113.0)
+        sx = inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]
+        sy = inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]
+        mov[y0:y1] = map_coordinates(ref, [sy, sx], order=1, mode="constant", cval=0.0, prefilter=False)
+
+    with ThreadPoolExecutor(max(1, min(8, os.cpu_count() or 1))) as ex:
+        list(ex.map(rows, range(0, H, band)))
+    scale = {np.dtype(np.uint8): 1.0, np.dtype(np.uint16): 60000 / 255.0, np.dtype(np.float32): 1.0}[np.dtype(dtype)]
+    cast = (lambda a: a) if np.dtype(dtype) == np.float32 else (lambda a: np.clip(np.rint(a * scale), 0, np.iinfo(dtype).max).astype(dtype))
+    return cast(ref), cast(mov), M

@@ -107,3 +107,34 @@ def test_cfg3_register_and_warp_equal_the_oracle():
     [16, 8, 4, 2, 1] = 1 + 9 + 25 + 81 + 289 windows, 269-chunk NMI gate, 289-window merge, pyrUp to 16384^2."""
     ref, mov = synthetic.make_pair(16384, 16384, 1)
     _compare(ref, mov, dict(num_pyr_lvl=4, use_full_res_img=True, use_dog=True), "cfg3 16384^2 f32 + DOG")
+
+
+def test_cfg5_mosaic_tiles_affine_init_then_optical_flow_refine():
+    """BASELINE cfg5 at its stated tile size: 4096^2 mosaic tiles, each misplaced by a known similarity (rotation
+    <= 0.5 deg, shift <= 20 px) plus a smooth residual; FeatureRegistrator (dense halves and the 2-NN search on the
+    device) supplies the affine initialisation, OptFlowRegistrator + Warper refine (parameters of cfg2), tiles dealt
+    by the sharded driver (parallel.align_pairs).  Checked: the recovered matrix against the known one, the residual
+    after each stage, and -- for the first tile -- the optical-flow stage against the oracle bit for bit on the very
+    image the affine stage produced."""
+    from microaligner_amd import parallel, transform_img_with_tmat
+    H = W = 4096
+    n_tiles = 3
+    tiles = [synthetic.make_mosaic_tile(H, W, seed=20 + i, dtype=np.uint16) for i in range(n_tiles)]
+    of_params = dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=False)
+    t0 = time.perf_counter()
+    out = parallel.align_pairs([(r, m) for r, m, _ in tiles], feature_params={}, optflow_params=of_params)
+    dt = time.perf_counter() - t0
+    print(f"\n[cfg5 {n_tiles} x 4096^2 u16] {dt / n_tiles:.2f} s per tile, numpy in / numpy out")
+    inner = (slice(300, -300), slice(300, -300))
+    for (ref, mov, M), (final, t_mat, flow) in zip(tiles, out):
+        Mi = np.linalg.inv(np.vstack([M, [0, 0, 1]]))[:2]
+        assert np.abs(t_mat[:, :2] - Mi[:, :2]).max() < 3e-4 and np.abs(t_mat[:, 2] - Mi[:, 2]).max() < 1.5
+        affine = transform_img_with_tmat(mov, (H, W), t_mat)
+        err = [np.abs(a[inner].astype(np.float64) - ref[inner]).mean() for a in (mov, affine, final)]
+        assert err[1] < 0.6 * err[0] and err[2] < 0.7 * err[1], err
+        assert final.dtype == np.uint16 and flow.shape == (H, W, 2)
+    ref, mov, _ = tiles[0]
+    affine = transform_img_with_tmat(mov, (H, W), out[0][1])
+    exp_flow, _ = RO.register(ref, affine, nthreads=CORES, **of_params)
+    assert np.array_equal(out[0][2], exp_flow)
+    assert np.array_equal(out[0][0], RO.warp(affine, exp_flow, 1000, 100))
