@@ -24,7 +24,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(out + "/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        key = next((k for k in ("fb_blur_h_solve", "fb_blur_v", "fb_polyexp_m0", "dog_cols_diff", "dog_rows") if k in n), None)
+        key = next((k for k in ("fb_blur_h_solve", "fb_blur_v", "fb_polyexp_m0", "dog_fused", "dog_cols_diff", "dog_rows") if k in n), None)
         if key:
             acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
 for k, d in acc.items():

@@ -22,6 +22,7 @@ GROUP = {"fb_polyexp_m0": "polyexp_m0", "fb_blur_v": "blur_v", "fb_blur_h_solve"
          "warp_tiled_kernel": "warp", "window_max_kernel": "merge", "cell_max_kernel": "merge",
          "window_from_cells_kernel": "merge", "merge_flows_kernel": "merge",
          "pyr_down_kernel": "pyr_down", "pyr_up_flow_kernel": "pyr_up", "dog_rows": "dog", "dog_cols_diff": "dog",
+         "dog_fused": "dog",
          "scale_to_u8": "dog", "minmax_partial": "dog", "minmax_final": "dog", "dog_params_in": "dog",
          "dog_params_out": "dog", "joint_hist_kernel": "nmi", "nmi_reduce_kernel": "nmi"}
 
