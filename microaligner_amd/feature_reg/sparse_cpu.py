@@ -5,18 +5,23 @@ The reference obtains these from opencv-contrib (feature_reg/feature_detection.p
 cv.FastFeatureDetector_create(threshold=1, nonmaxSuppression=True, TYPE_9_16), cv.xfeatures2d.DAISY_create(radius=21,
 q_radius=3, q_theta=8, q_hist=8, NRM_NONE, interpolation=True, use_orientation=False), cv.FlannBasedMatcher +
 Lowe's ratio 0.5, cv.estimateAffinePartial2D(RANSAC, confidence=0.99).  opencv-contrib is not available to this
-build, so the stage is restated here from the published algorithms.  It is a sparse, irregular CPU workload (a few
-thousand points per tile), deliberately NOT on the GPU; the dense pieces around it (DOG, pyramids, warpAffine, the
-NMI gate) are.  PARITY UNPINNED: FAST follows OpenCV's segment test, score and 3x3 non-maximum suppression exactly
+build, so the stage is restated here from the published algorithms.  This module is the HOST statement of that
+stage and the definition its device counterparts are tested against: csrc/daisy.hip (FAST score map + non-maximum
+suppression, DAISY layers / smoothing / sampling, all tiles of a level in one batch) and csrc/knn.hip (the exact 2-NN
+search) reproduce it bit for bit and are what FeatureRegistrator runs; corner selection, the ratio test and RANSAC --
+a few thousand points -- stay here.  PARITY UNPINNED: FAST follows OpenCV's segment test, score and 3x3 non-maximum suppression exactly
 as published; DAISY follows Tola et al. (PAMI 2010) with OpenCV's parameter meaning but not its exact smoothing
 schedule; matching is exact 2-NN where FLANN is approximate; RANSAC uses its own random sequence.  The outputs are
 therefore functionally equivalent (same kind of keypoints, descriptors and 2x3 similarity transform), not
 bit-identical to opencv-contrib.
 """
+import threading
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
 import numpy as np
+
+_BLAS_LOCK = threading.Lock()
 
 # Bresenham circle of radius 3, OpenCV's order (dx, dy)
 _RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1),
@@ -169,7 +174,8 @@ def knn2(query: np.ndarray, train: np.ndarray, block: int = 1024):
     tn = np.einsum("ij,ij->i", t, t)
     idx = np.empty((len(q), 2), np.int64)
     dist = np.empty((len(q), 2), np.float32)
-    with _blas_threads(16):
+    # threadpool_limits is process-global and not re-entrant across threads: one search at a time holds the cap
+    with _BLAS_LOCK, _blas_threads(16):
         _knn2_blocks(q, t, tn, idx, dist, block)
     return idx, dist
 
