@@ -59,11 +59,6 @@ int ma_device_count(int* count);
 int ma_ctx_create(int device, ma_ctx** out);
 void ma_ctx_destroy(ma_ctx* ctx);
 int ma_sync(ma_ctx* ctx);
-/* Stream order between two contexts of one device: work enqueued on `waiter` after this call starts only when
- * everything enqueued on `signaller` before it has finished.  Does not block the host.  (register() runs the
- * "before" half of its similarity gate -- dog(raw moving level) + NMI, optflow_registrator.py:129-130 -- on a second
- * context while the Farneback kernels of the level occupy the first.) */
-int ma_ctx_wait_for(ma_ctx* waiter, ma_ctx* signaller);
 /* Upper bound, in bytes, for the internal tile-batch workspace (default 48 GiB). */
 int ma_ctx_set_workspace_limit(ma_ctx* ctx, size_t bytes);
 /* The ctx's hipStream_t as an opaque pointer (for event timing by the caller). */

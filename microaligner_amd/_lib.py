@@ -26,7 +26,6 @@ SIGNATURES = {
     "ma_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "ma_ctx_destroy": (None, [_vp]),
     "ma_sync": (_i, [_vp]),
-    "ma_ctx_wait_for": (_i, [_vp, _vp]),
     "ma_ctx_set_workspace_limit": (_i, [_vp, _sz]),
     "ma_ctx_stream": (_vp, [_vp]),
     "ma_malloc": (_i, [_vp, _sz, C.POINTER(_vp)]),

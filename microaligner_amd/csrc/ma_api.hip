@@ -81,21 +81,6 @@ int ma_sync(ma_ctx* ctx)
     return MA_OK;
 }
 
-int ma_ctx_wait_for(ma_ctx* waiter, ma_ctx* signaller)
-{
-    MA_REQUIRE(waiter && signaller, "NULL argument");
-    if (waiter == signaller) return MA_OK;
-    MA_REQUIRE(waiter->device == signaller->device, "both contexts must drive the same device");
-    MA_HIP(hipSetDevice(waiter->device));
-    hipEvent_t ev;
-    MA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    hipError_t e = hipEventRecord(ev, signaller->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(waiter->stream, ev, 0);
-    (void)hipEventDestroy(ev);   // released once the wait has been satisfied
-    if (e != hipSuccess) { ma_set_error("stream wait failed: %s", hipGetErrorString(e)); return MA_EHIP; }
-    return MA_OK;
-}
-
 int ma_ctx_set_workspace_limit(ma_ctx* ctx, size_t bytes)
 {
     MA_REQUIRE(ctx, "ctx is NULL");

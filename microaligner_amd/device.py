@@ -119,8 +119,6 @@ class Context:
         self._host_pool = {}   # bucket -> [pinned host pointers] (result arrays of the numpy-in / numpy-out API)
         self._host_lock = threading.Lock()
         self._closed = False
-        self._side = None      # lazily created companion context + its worker thread (side_context())
-        self._side_pool = None
         lim = os.environ.get("MICROALIGNER_WORKSPACE_GB")
         if lim:
             L.check(self.lib.ma_ctx_set_workspace_limit(self.handle, int(float(lim) * (1 << 30))))
@@ -225,25 +223,8 @@ class Context:
     def sync(self):
         L.check(self.lib.ma_sync(self.handle))
 
-    def wait_for(self, other):
-        """Stream order: what is enqueued here from now on starts after what `other` has enqueued so far."""
-        L.check(self.lib.ma_ctx_wait_for(self.handle, other.handle))
-
-    def side_context(self):
-        """A companion context on the same device (own stream, workspace and pool) and a one-thread executor that
-        drives it: independent branches of one computation run there while this context's stream is busy."""
-        if self._side is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._side = Context(self.device)
-            self._side_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="ma-side")
-        return self._side, self._side_pool
-
     def close(self):
         if not self._closed:
-            if self._side is not None:
-                self._side_pool.shutdown(wait=True)
-                self._side.close()
-                self._side = None
             L.check(self.lib.ma_sync(self.handle))
             self.trim()
             # arrays that outlive the context: their HBM goes back to the driver now (they raise if used again)
@@ -275,26 +256,16 @@ class Context:
 
     def profile(self, on=True):
         L.check(self.lib.ma_profile_enable(self.handle, int(on)))
-        if self._side is not None:
-            self._side.profile(on)
 
     def profile_reset(self):
         L.check(self.lib.ma_profile_reset(self.handle))
-        if self._side is not None:
-            self._side.profile_reset()
 
     def profile_get(self):
-        """Accumulated per-kernel time / launches / pixels, the companion context's kernels included (their
-        durations are measured while kernels of this context share the GPU with them)."""
         out = {}
         for name, kid in L.KERNEL_IDS.items():
             ms, n, px = C.c_double(), C.c_longlong(), C.c_double()
             L.check(self.lib.ma_profile_get(self.handle, kid, C.byref(ms), C.byref(n), C.byref(px)))
             out[name] = {"ms": ms.value, "launches": n.value, "px": px.value}
-        if self._side is not None:
-            for name, rec in self._side.profile_get().items():
-                for k in rec:
-                    out[name][k] += rec[k]
         return out
 
     # -- primitives (device in, device out) ---------------------------------------------------

@@ -9,7 +9,6 @@ array stays in HBM between the steps of a level and every step is a HIP kernel p
 including its quirks (Q1 absolute-coordinate flow merge, Q2 no x2 when upscaling to
 full resolution, Q3 x4 in the middle-level reject branch).
 """
-import os
 from dataclasses import dataclass
 from math import log2
 from typing import List, Optional, Tuple
@@ -55,8 +54,6 @@ class OptFlowRegistrator:
         # additions (defaults keep the reference's behaviour)
         self.verbose = True            # the reference prints per-level progress
         self.muladd_fused = False      # window blur with FMA (see MA_FB_MULADD_FUSED)
-        # "before" half of the gate on a companion stream during the Farneback kernels (MICROALIGNER_OVERLAP_GATE=0: off)
-        self.overlap_gate = os.environ.get("MICROALIGNER_OVERLAP_GATE", "1") != "0"
         self.level_reports: List[LevelReport] = []
         self._warper = Warper()
         self._tile_flow_calc = TileFlowCalc()
@@ -135,10 +132,6 @@ class OptFlowRegistrator:
             mov_lvl = mov_raw if lvl == 0 else self._warp(mov_raw, m_flow)
 
             ref_dog = self._dog_dev(ref_lvl)  # needed by the gate; doubles as Farneback input if use_dog
-            # The "before" score, mi(dog(ref), dog(raw moving level)) (:130), depends on nothing this level computes:
-            # it runs on the companion context (own stream / workspace) while the Farneback kernels -- bound by
-            # packed-FP32 issue, with idle memory pipes -- keep this one busy.  Same kernels, same bits.
-            before_job = self._start_before(ctx, ref_dog, mov_raw) if self.overlap_gate else None
             fc = self._tile_flow_calc
             fc.ref_img = ref_dog if self.use_dog else ref_lvl
             fc.mov_img = self._dog_dev(mov_lvl) if self.use_dog else mov_lvl
@@ -147,8 +140,7 @@ class OptFlowRegistrator:
             mov_warped = self._warp(mov_lvl, this_flow)
             # gate (optflow_registrator.py:127-132): "before" is the RAW level, not the pre-warped one
             after = mi_tiled(ref_dog, self._dog_dev(mov_warped), self.tile_size)
-            before = before_job.result() if before_job is not None else \
-                mi_tiled(ref_dog, self._dog_dev(mov_raw), self.tile_size)
+            before = mi_tiled(ref_dog, self._dog_dev(mov_raw), self.tile_size)
             self._log("    MI score after:", after, "| MI score before:", before)
             accepted = bool(after > before)
             self.level_reports.append(LevelReport(factor, tuple(ref_lvl.shape), float(after), float(before), accepted))
@@ -178,18 +170,6 @@ class OptFlowRegistrator:
         result = m_flow
         self._ctx = None
         return result if device_in else result.numpy()
-
-    def _start_before(self, ctx, ref_dog, mov_raw):
-        from ..device import use_context
-        side, pool = ctx.side_context()
-        side.wait_for(ctx)          # ref_dog and the pyramid level are ready on ctx's stream by then
-        tile = self.tile_size
-
-        def job():
-            with use_context(side):
-                return mi_tiled(ref_dog, side.dog_u8(mov_raw), tile)   # reads back on the companion stream only
-
-        return pool.submit(job)
 
     # -- pieces ---------------------------------------------------------------------------------
     def _generate_img_pyr(self, arr) -> Tuple[list, List[int]]:
