@@ -117,6 +117,7 @@ class Context:
         self._pool = {}
         self._live = {}        # ptr -> bucket of every buffer handed out and not yet released
         self._host_pool = {}   # bucket -> [pinned host pointers] (result arrays of the numpy-in / numpy-out API)
+        self._host_owned = {}  # bucket -> page-locked buffers this context owns (handed out + pooled)
         self._host_lock = threading.Lock()
         self._closed = False
         lim = os.environ.get("MICROALIGNER_WORKSPACE_GB")
@@ -173,6 +174,8 @@ class Context:
         self._pool = {}
         with self._host_lock:
             pools, self._host_pool = self._host_pool, {}
+            for bucket, free in pools.items():
+                self._host_owned[bucket] = self._host_owned.get(bucket, 0) - len(free)
         for free in pools.values():
             for p in free:
                 self.lib.ma_host_free(p)
@@ -187,7 +190,11 @@ class Context:
         L.check(rc)
 
     # page-locked result arrays ---------------------------------------------------------------
-    HOST_POOL_PER_BUCKET = 3
+    # Page-locked buffers of one size that a context will own at any time (handed out or pooled).  Pinning is far
+    # dearer than a page fault per 4 KiB (hipHostMalloc: ~200 ms per GiB; faulting a fresh pageable array: ~25 ms per GiB), so
+    # it only pays for buffers that are reused: a caller that keeps accumulating results gets pageable arrays beyond
+    # this number, a loop that drops each result before the next but one reuses the same two buffers forever.
+    HOST_PINNED_PER_BUCKET = 2
 
     def host_empty(self, shape, dtype):
         """ndarray on page-locked host memory drawn from a pool.  The memory returns to the pool when the array
@@ -203,10 +210,16 @@ class Context:
         with self._host_lock:
             free = self._host_pool.get(bucket)
             ptr = free.pop() if free else None
+            if ptr is None:
+                if self._host_owned.get(bucket, 0) >= self.HOST_PINNED_PER_BUCKET:
+                    return np.empty(shape, dtype)
+                self._host_owned[bucket] = self._host_owned.get(bucket, 0) + 1
         if ptr is None:
             p = C.c_void_p()
             rc = self.lib.ma_host_alloc(bucket, C.byref(p))
             if rc != L.MA_OK:           # page-locked memory exhausted: fall back to a pageable array
+                with self._host_lock:
+                    self._host_owned[bucket] -= 1
                 return np.empty(shape, dtype)
             ptr = p.value
         owner = _HostBuffer(self, ptr, bucket, nbytes)
@@ -214,9 +227,8 @@ class Context:
 
     def _host_release(self, ptr, bucket):
         with self._host_lock:
-            free = self._host_pool.setdefault(bucket, [])
-            if not self._closed and len(free) < self.HOST_POOL_PER_BUCKET:
-                free.append(ptr)
+            if not self._closed:
+                self._host_pool.setdefault(bucket, []).append(ptr)
                 return
         self.lib.ma_host_free(ptr)
 
