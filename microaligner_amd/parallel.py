@@ -34,10 +34,28 @@ def shard(n_units: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, n_units, world_size))
 
 
-def _make_lane_context():
-    """A fresh context (own HIP stream, workspace, buffer pool) on this process's device."""
+_lane_contexts = {}   # (device, lane index) -> Context, kept for the life of the process (release_lane_contexts())
+
+
+def _lane_context(k: int):
+    """The context (own HIP stream, workspace, buffer pools) of lane k on this process's device.  Lane 0 is the
+    process-wide context; the others are created on first use and kept: a context's workspace (tens of GB for
+    16384^2 pairs) and its page-locked result buffers are expensive to set up, and callers come back."""
     from .device import Context, get_context
-    return Context(get_context().device)
+    base = get_context()
+    if k == 0:
+        return base
+    key = (base.device, k)
+    ctx = _lane_contexts.get(key)
+    if ctx is None or ctx._closed:
+        ctx = _lane_contexts[key] = Context(base.device)
+    return ctx
+
+
+def release_lane_contexts():
+    """Close the cached lane contexts (their HBM workspaces and page-locked buffers go back to the driver)."""
+    for key in list(_lane_contexts):
+        _lane_contexts.pop(key).close()
 
 
 def _run_local(units: Sequence, mine: List[int], fn: Callable, lanes: int):
@@ -50,24 +68,23 @@ def _run_local(units: Sequence, mine: List[int], fn: Callable, lanes: int):
     from .device import use_context
     todo, lock, results, errors = list(reversed(mine)), threading.Lock(), {}, []
 
-    def worker():
-        ctx = None
+    nl = min(lanes, len(mine))
+    ctxs = [_lane_context(k) for k in range(nl)]   # created here, on the calling thread, one after the other
+
+    def worker(k):
         try:
-            ctx = _make_lane_context()
-            with use_context(ctx):
+            with use_context(ctxs[k]):
                 while not errors:
                     with lock:
                         if not todo:
                             break
                         i = todo.pop()
                     results[i] = fn(units[i])
+                ctxs[k].sync()
         except BaseException as e:  # surfaced on the calling thread
             errors.append(e)
-        finally:
-            if ctx is not None:
-                ctx.close()
 
-    threads = [threading.Thread(target=worker, name=f"ma-lane-{k}") for k in range(min(lanes, len(mine)))]
+    threads = [threading.Thread(target=worker, args=(k,), name=f"ma-lane-{k}") for k in range(nl)]
     for t in threads:
         t.start()
     for t in threads:

@@ -90,15 +90,18 @@ def test_lanes_run_every_unit_once_under_their_own_context(monkeypatch):
     from microaligner_amd import device, parallel
 
     class FakeCtx:
-        made, closed = [], []
+        made, synced = {}, []
 
-        def __init__(self):
-            FakeCtx.made.append(self)
+        def __init__(self, k):
+            self.k = k
 
-        def close(self):
-            FakeCtx.closed.append(self)
+        def sync(self):
+            FakeCtx.synced.append(self.k)
 
-    monkeypatch.setattr(parallel, "_make_lane_context", FakeCtx)
+    def lane_context(k):     # lane contexts are cached: the same lane index yields the same context
+        return FakeCtx.made.setdefault(k, FakeCtx(k))
+
+    monkeypatch.setattr(parallel, "_lane_context", lane_context)
     seen = {}
 
     def fn(u):
@@ -107,7 +110,8 @@ def test_lanes_run_every_unit_once_under_their_own_context(monkeypatch):
 
     out = parallel.run_sharded(list(range(11)), fn, gather=True, lanes=3)
     assert out == [u * u for u in range(11)]
-    assert len(FakeCtx.made) == 3 and FakeCtx.closed and set(FakeCtx.closed) == set(FakeCtx.made)
+    assert sorted(FakeCtx.made) == [0, 1, 2] and sorted(FakeCtx.synced) == [0, 1, 2]
+    assert len({id(c) for _, c in seen.values()}) == 3
     assert all(name.startswith("ma-lane-") and isinstance(c, FakeCtx) for name, c in seen.values())
     assert getattr(device._tls, "ctx", None) is None            # nothing leaks onto the calling thread
 
