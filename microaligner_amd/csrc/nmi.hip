@@ -8,54 +8,53 @@
 
 namespace {
 
-// Joint histogram with LDS privatisation.  grid: (4 label bands x pixel slices, chunks).  A block owns the
-// 64 x 256 band of the chunk's 256 x 256 histogram whose first label is in [64*band, 64*band+64): 64 KiB of u32
-// counters in LDS, filled with LDS atomics from its pixel slice (every band re-reads the slice: 8 B/px of
-// traffic instead of one global atomic per pixel), then the non-zero counters are added to the chunk's
-// histogram in HBM.  Lanes read 16 consecutive pixels each (one 16-byte load per array) so that the 64 lanes
-// of an LDS-atomic instruction hit pixels 16 apart, which decorrelates the bins on smooth DOG images.
-constexpr int HIST_SLICE = 1 << 17;  // pixels per block slice
-__global__ __launch_bounds__(256) void joint_hist_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-                                                         size_t n, size_t chunk, unsigned* __restrict__ hist)
+// Joint histogram with LDS privatisation, one pass over the pixels.  grid: (pixel slices, chunks).  A block holds the
+// whole 256 x 256 joint histogram of its slice in LDS as 16-bit counters packed two to a word (128 KiB): a slice has
+// at most 65 520 pixels, so no counter can reach 2^16 and a plain 32-bit LDS atomic add of 1 << 16 * (bin & 1) never
+// carries into its neighbour.  Every pixel is read and decoded once (2 B/px of HBM traffic = the algorithmic bytes;
+// the round-1 kernel kept 32-bit counters for a quarter of the labels and read every slice four times); then the
+// non-zero counters are added to the chunk's histogram in HBM.  Lanes read 16 consecutive pixels each (one 16-byte
+// load per array) so that the 64 lanes of an LDS-atomic instruction hit pixels 16 apart, which decorrelates the bins
+// on smooth DOG images.  Measured alternatives (profiles/r02_notes.md): two label bands of 32-bit counters 0.167 ms
+// per launch, this kernel 0.171, the four-band kernel 0.281.
+constexpr int HIST_SLICE16 = 65520;
+template <int NT>
+__global__ __launch_bounds__(NT) void joint_hist16_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                          size_t n, size_t chunk, unsigned* __restrict__ hist)
 {
-    __shared__ unsigned h[64 * 256];
-    const unsigned band = blockIdx.x & 3, slice = blockIdx.x >> 2;
+    extern __shared__ unsigned h[];              // [256 * 256 / 2]
     const size_t c0 = (size_t)blockIdx.y * chunk;
     const size_t c1 = c0 + chunk < n ? c0 + chunk : n;
-    size_t s0 = c0 + (size_t)slice * HIST_SLICE;
-    const size_t s1 = s0 + HIST_SLICE < c1 ? s0 + HIST_SLICE : c1;
+    size_t s0 = c0 + (size_t)blockIdx.x * HIST_SLICE16;
+    const size_t s1 = s0 + HIST_SLICE16 < c1 ? s0 + HIST_SLICE16 : c1;
     if (s0 >= s1) return;
-    for (int i = threadIdx.x; i < 64 * 256; i += 256) h[i] = 0;
+    for (int i = threadIdx.x; i < 32768; i += NT) h[i] = 0;
     __syncthreads();
-    // unaligned head (the chunk start need not be 16-byte aligned)
+    auto count = [&](unsigned ai, unsigned bi) {
+        const unsigned bin = ai * 256u + bi;
+        atomicAdd(&h[bin >> 1], 1u << ((bin & 1u) * 16u));
+    };
     size_t al = (s0 + 15) & ~(size_t)15;
     if (al > s1) al = s1;
-    for (size_t i = s0 + threadIdx.x; i < al; i += 256) {
-        unsigned av = a[i];
-        if ((av >> 6) == band) atomicAdd(&h[(av & 63u) * 256u + b[i]], 1u);
-    }
+    for (size_t i = s0 + threadIdx.x; i < al; i += NT) count(a[i], b[i]);
     const bool vec_ok = (((size_t)a | (size_t)b) & 15) == 0;
     const size_t nvec = vec_ok ? (s1 - al) / 16 : 0;
     const uint4* a4 = (const uint4*)(a + al);
     const uint4* b4 = (const uint4*)(b + al);
-    for (size_t v = threadIdx.x; v < nvec; v += 256) {
+    for (size_t v = threadIdx.x; v < nvec; v += NT) {
         const uint4 av = a4[v], bv = b4[v];
         const unsigned aw[4] = {av.x, av.y, av.z, av.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            unsigned ai = (aw[k >> 2] >> ((k & 3) * 8)) & 255u, bi = (bw[k >> 2] >> ((k & 3) * 8)) & 255u;
-            if ((ai >> 6) == band) atomicAdd(&h[(ai & 63u) * 256u + bi], 1u);
-        }
+        for (int k = 0; k < 16; k++)
+            count((aw[k >> 2] >> ((k & 3) * 8)) & 255u, (bw[k >> 2] >> ((k & 3) * 8)) & 255u);
     }
-    for (size_t i = al + nvec * 16 + threadIdx.x; i < s1; i += 256) {
-        unsigned av = a[i];
-        if ((av >> 6) == band) atomicAdd(&h[(av & 63u) * 256u + b[i]], 1u);
-    }
+    for (size_t i = al + nvec * 16 + threadIdx.x; i < s1; i += NT) count(a[i], b[i]);
     __syncthreads();
-    unsigned* hh = hist + (size_t)blockIdx.y * 65536 + band * (64 * 256);
-    for (int i = threadIdx.x; i < 64 * 256; i += 256) {
-        unsigned c = h[i];
-        if (c) atomicAdd(&hh[i], c);
+    unsigned* hh = hist + (size_t)blockIdx.y * 65536;
+    for (int i = threadIdx.x; i < 32768; i += NT) {
+        const unsigned c = h[i];
+        if (c & 0xffffu) atomicAdd(&hh[2 * i], c & 0xffffu);
+        if (c >> 16) atomicAdd(&hh[2 * i + 1], c >> 16);
     }
 }
 
@@ -180,10 +179,10 @@ int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t 
     {
         MaProfScope ps(ctx, MA_K_NMI, (double)n);
         MA_HIP(hipMemsetAsync(hist, 0, hist_bytes, ctx->stream));
-        const size_t slices = (chunk + HIST_SLICE - 1) / HIST_SLICE;
-        MA_REQUIRE(slices * 4 <= 0x7fffffff, "chunk too large");
-        hipLaunchKernelGGL(joint_hist_kernel, dim3((unsigned)(slices * 4), (unsigned)nchunks), dim3(256), 0, ctx->stream,
-                           a, b, n, chunk, hist);
+        const size_t slices = (chunk + HIST_SLICE16 - 1) / HIST_SLICE16;
+        MA_REQUIRE(slices <= 0x7fffffff, "chunk too large");
+        hipLaunchKernelGGL((joint_hist16_kernel<1024>), dim3((unsigned)slices, (unsigned)nchunks), dim3(1024),
+                           32768 * sizeof(unsigned), ctx->stream, a, b, n, chunk, hist);
         hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)nchunks), dim3(NR_T), 0, ctx->stream, hist, n, chunk, scores);
         MA_HIP(hipGetLastError());
     }
