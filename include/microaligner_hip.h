@@ -137,6 +137,15 @@ int ma_remap_bilinear(ma_ctx* ctx, const void* src, int dtype, int cn, int sh, i
 int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow,
                   int tile, int overlap, void* out);
 
+/* ma_warp_tiled that also leaves by-products on the device for the steps that follow it inside register():
+ * minmax_dev (may be NULL): (min, max) of the warped image, which the dog() of that image takes (ma_dog_u8_minmax);
+ * flow_cellkeys_dev: maximum of both FLOW components over the (2*ntx+1) x (2*nty+1) cells the window borders
+ * k*tile -+ overlap cut the image into (row-major, order-preserving unsigned keys, NaN = largest), from which
+ * ma_merge_flows_tiled_cells derives the per-window flow.max() tests of merge_two_flows
+ * (optflow_registrator.py:38-42) without reading the flows again.  Requires tile > 2*overlap > 0. */
+int ma_warp_tiled_flowcells(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile,
+                            int overlap, void* out, float* minmax_dev, unsigned* flow_cellkeys_dev);
+
 /* Page-warp driver, warp_and_save_pages (__main__.py:288-302, 427-433): warps n_pages HOST images (the channel
  * and z pages of one cycle) with ONE device-resident flow, writing into caller-provided HOST buffers (e.g. rows
  * of the memmapped output TIFF).  H2D, kernel and D2H of consecutive pages overlap on internal streams.
@@ -149,6 +158,9 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
  * flow1.max()==0, flow1 if flow2.max()==0, else flow1 + remap(flow2, -flow1). */
 int ma_merge_flows_tiled(ma_ctx* ctx, const float* flow1, const float* flow2, int H, int W,
                          int tile, int overlap, float* out);
+/* Same result with the cell maxima of both flows already on the device (ma_warp_tiled_flowcells). */
+int ma_merge_flows_tiled_cells(ma_ctx* ctx, const float* flow1, const float* flow2, int H, int W, int tile, int overlap,
+                               const unsigned* cellkeys1, const unsigned* cellkeys2, float* out);
 
 /* ---- pyramids -------------------------------------------------------------
  * cv2.pyrDown(img) (optflow_registrator.py:194): dst is ((h+1)/2, (w+1)/2). */

@@ -59,6 +59,8 @@ SIGNATURES = {
     "ma_normalize_minmax_u8": (_i, [_vp, _vp, _i, _sz, _vp]),
     "ma_warp_affine": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _vp]),
     "ma_warp_tiled_minmax": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "ma_warp_tiled_flowcells": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "ma_merge_flows_tiled_cells": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ma_pyr_down_minmax": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ma_dog_u8_minmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "ma_warp_affine_cv": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _i, _i, _vp]),

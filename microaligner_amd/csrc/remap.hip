@@ -159,15 +159,44 @@ __device__ __forceinline__ T warp_tiled_px(const T* __restrict__ img, const MaTi
     return res;
 }
 
+// floats <-> unsigned keys whose integer order is the float order (so atomicMax works for any sign); every NaN maps
+// to the largest key, so it survives the atomic reduction (numpy's .max() propagates NaN)
+__device__ __forceinline__ unsigned f2key(float f)
+{
+    if (f != f) return 0xffffffffu;
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// NaN-propagating maximum (fmaxf drops NaNs)
+__device__ __forceinline__ float d_max_nan(float m, float v) { return (m != m || v != v) ? NAN : fmaxf(m, v); }
+// Segment of coordinate v along an axis cut at the window borders k*T - ov and k*T + ov (T > 2*ov):
+// zone_k = [k*T - ov, k*T + ov) has index 2k, core_k = [k*T + ov, (k+1)*T - ov) index 2k+1; window t is the union of
+// segments 2t, 2t+1, 2t+2 (see cell_max_kernel).
+__device__ __forceinline__ int d_segment(int v, int T, int ov)
+{
+    const int k = (v + ov) / T;
+    return 2 * k + ((v + ov - k * T) >= 2 * ov ? 1 : 0);
+}
+
 // WARP_ROWS rows per thread: the flow loads of all rows are issued before the first gather, the gathers of all
 // rows before the first store -- 8 rows in flight per thread run 1.4x faster than one (measured, profiles/r01_notes.md)
 constexpr int WARP_ROWS = 8;
 // MM: also reduce (min, max) of the block's output pixels into part[2 * block] (input conditioning of a following
 // dog(): the consumer then skips its own pass over the image)
+// cellkeys (may be NULL; needs T > 2*ov > 0): also fold the maximum of both FLOW components over the cells the window
+// borders cut the image into, cellkeys[segy * nsegx + segx] (zero-initialised keys, f2key order).  Every flow that
+// the registration merges passes through this kernel first (the pre-warp of a level reads the accumulated flow, the
+// gate's warp reads the level's flow), so _merge_flow_in_tiles' per-window .max() tests (optflow_registrator.py:
+// 38-42) need no pass of their own over the two flows.
 template <typename T, bool MM>
 __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ img, MaTiling g,
                                                          const float2* __restrict__ flow, T* __restrict__ out,
-                                                         float* __restrict__ part)
+                                                         float* __restrict__ part, unsigned* __restrict__ cellkeys,
+                                                         int nsegx)
 {
     constexpr int WR = WARP_ROWS;
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * WR;
@@ -179,6 +208,31 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
         float2 f[WR];
 #pragma unroll
         for (int r = 0; r < WR; r++) f[r] = flow[(size_t)min(y0 + r, g.H - 1) * g.W + x];
+        if (cellkeys) {
+            const int ylast = min(y0 + WR - 1, g.H - 1);
+            const int sy0 = d_segment(y0, g.T, g.ov), sx = d_segment(x, g.T, g.ov);
+            if (sy0 == d_segment(ylast, g.T, g.ov)) {
+                // the block's rows share a y segment: one value per thread, one atomic per wave where the wave's
+                // columns share an x segment too (segments are >= 2*ov wide: the common case)
+                float m = d_max_nan(f[0].x, f[0].y);
+#pragma unroll
+                for (int r = 1; r < WR; r++)
+                    if (y0 + r < g.H) m = d_max_nan(m, d_max_nan(f[r].x, f[r].y));
+                const int sx_first = __shfl(sx, 0), sx_last = __shfl(sx, 63);
+                const bool full = __builtin_amdgcn_readfirstlane(__popcll(__ballot(1))) == 64;
+                if (full && sx_first == sx_last) {
+                    for (int off = 32; off > 0; off >>= 1) m = d_max_nan(m, __shfl_down(m, off));
+                    if ((threadIdx.x & 63) == 0) atomicMax(&cellkeys[(size_t)sy0 * nsegx + sx], f2key(m));
+                } else {
+                    atomicMax(&cellkeys[(size_t)sy0 * nsegx + sx], f2key(m));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if (y0 + r < g.H)
+                        atomicMax(&cellkeys[(size_t)d_segment(y0 + r, g.T, g.ov) * nsegx + sx], f2key(d_max_nan(f[r].x, f[r].y)));
+            }
+        }
         T res[WR];
 #pragma unroll
         for (int r = 0; r < WR; r++) {
@@ -200,21 +254,6 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
 // per window: max over the zero-padded window of both flow components with numpy's .max() semantics: a NaN
 // anywhere in the window makes the maximum NaN, `nan == 0` is False and the window takes the general remap branch
 // (optflow_registrator.py:38-47).
-// floats <-> unsigned keys whose integer order is the float order (so atomicMax works for any sign); every NaN maps
-// to the largest key, so it survives the atomic reduction
-__device__ __forceinline__ unsigned f2key(float f)
-{
-    if (f != f) return 0xffffffffu;
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-// NaN-propagating maximum (fmaxf drops NaNs)
-__device__ __forceinline__ float d_max_nan(float m, float v) { return (m != m || v != v) ? NAN : fmaxf(m, v); }
-__device__ __forceinline__ float key2f(unsigned k)
-{
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
 // grid: (window, row band of WM_ROWS rows); maxkeys[2*window + {0,1}] must be zero-initialised
 // (key 0 decodes to a NaN that loses against every real value's key).
 constexpr int WM_ROWS = 64;
@@ -291,8 +330,11 @@ __global__ __launch_bounds__(256) void cell_max_kernel(const float2* __restrict_
     }
 }
 // one thread per window: max over its 3 x 3 cells; zero padding takes part in numpy's .max()
-__global__ void window_from_cells_kernel(const unsigned* __restrict__ cellkeys, MaTiling g, int nsegx,
-                                         unsigned* __restrict__ maxkeys)
+// STRIDE = 2: cellkeys holds (flow1, flow2) pairs per cell (cell_max_kernel); STRIDE = 1: one array per flow (the
+// by-product of warp_tiled_kernel)
+template <int STRIDE>
+__global__ void window_from_cells_kernel(const unsigned* __restrict__ cellkeys, const unsigned* __restrict__ cellkeys2,
+                                         MaTiling g, int nsegx, unsigned* __restrict__ maxkeys)
 {
     const int widx = blockIdx.x * blockDim.x + threadIdx.x;
     if (widx >= g.ntx * g.nty) return;
@@ -302,8 +344,9 @@ __global__ void window_from_cells_kernel(const unsigned* __restrict__ cellkeys, 
     unsigned k1 = padded ? f2key(0.f) : 0u, k2 = k1;
     for (int j = 0; j < 3; j++)
         for (int i = 0; i < 3; i++) {
-            const unsigned* c = cellkeys + ((size_t)(2 * ty + j) * nsegx + 2 * tx + i) * 2;
-            k1 = max(k1, c[0]); k2 = max(k2, c[1]);
+            const size_t cell = (size_t)(2 * ty + j) * nsegx + 2 * tx + i;
+            if (STRIDE == 2) { k1 = max(k1, cellkeys[cell * 2]); k2 = max(k2, cellkeys[cell * 2 + 1]); }
+            else { k1 = max(k1, cellkeys[cell]); k2 = max(k2, cellkeys2[cell]); }
         }
     maxkeys[widx * 2] = k1;
     maxkeys[widx * 2 + 1] = k2;
@@ -414,7 +457,7 @@ int ma_warp_affine_cv(ma_ctx* ctx, const void* src, int dtype, int sh, int sw, c
 }
 
 static int warp_tiled_impl(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile, int overlap,
-                           void* out, float* minmax_dev)
+                           void* out, float* minmax_dev, unsigned* flow_cellkeys_dev = nullptr)
 {
     MA_REQUIRE(ctx && img && flow && out, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
@@ -430,10 +473,15 @@ static int warp_tiled_impl(ma_ctx* ctx, const void* img, int dtype, int H, int W
         MA_TRY(ma_ws_reserve(ctx, nblk * 2 * sizeof(float)));
         part = (float*)ctx->ws;
     }
+    const int nsegx = 2 * g.ntx + 1, nsegy = 2 * g.nty + 1;
+    if (flow_cellkeys_dev) MA_REQUIRE(tile > 2 * overlap && overlap > 0, "flow cell maxima need tile > 2*overlap > 0");
     MaProfScope ps(ctx, MA_K_WARP, (double)H * W);
+    if (flow_cellkeys_dev)
+        MA_HIP(hipMemsetAsync(flow_cellkeys_dev, 0, (size_t)nsegx * nsegy * sizeof(unsigned), ctx->stream));
     const float2* f = (const float2*)flow;
-#define MA_WARP(T) do { if (part) hipLaunchKernelGGL((warp_tiled_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part); \
-                        else hipLaunchKernelGGL((warp_tiled_kernel<T, false>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part); } while (0)
+    unsigned* ck = flow_cellkeys_dev;
+#define MA_WARP(T) do { if (part) hipLaunchKernelGGL((warp_tiled_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part, ck, nsegx); \
+                        else hipLaunchKernelGGL((warp_tiled_kernel<T, false>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part, ck, nsegx); } while (0)
     if (dtype == MA_U8) MA_WARP(uint8_t);
     else if (dtype == MA_U16) MA_WARP(uint16_t);
     else MA_WARP(float);
@@ -454,6 +502,13 @@ int ma_warp_tiled_minmax(ma_ctx* ctx, const void* img, int dtype, int H, int W, 
 {
     MA_REQUIRE(minmax_dev, "NULL argument");
     return warp_tiled_impl(ctx, img, dtype, H, W, flow, tile, overlap, out, minmax_dev);
+}
+
+int ma_warp_tiled_flowcells(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile,
+                            int overlap, void* out, float* minmax_dev, unsigned* flow_cellkeys_dev)
+{
+    MA_REQUIRE(flow_cellkeys_dev, "NULL argument");
+    return warp_tiled_impl(ctx, img, dtype, H, W, flow, tile, overlap, out, minmax_dev, flow_cellkeys_dev);
 }
 
 // ---- page-warp driver ---------------------------------------------------------------------
@@ -502,9 +557,9 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
     for (int i = 0; i < n_pages; i++) {
         Slot& s = slots[i % ns];  // stream order keeps the slot's buffers safe: copy-in waits for the previous copy-out
         PG_HIP(hipMemcpyAsync(s.din, pages_host[i], nb, hipMemcpyHostToDevice, s.st));
-        if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t, false>), grid, block, 0, s.st, (const uint8_t*)s.din, g, f, (uint8_t*)s.dout, (float*)nullptr);
-        else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t, false>), grid, block, 0, s.st, (const uint16_t*)s.din, g, f, (uint16_t*)s.dout, (float*)nullptr);
-        else hipLaunchKernelGGL((warp_tiled_kernel<float, false>), grid, block, 0, s.st, (const float*)s.din, g, f, (float*)s.dout, (float*)nullptr);
+        if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t, false>), grid, block, 0, s.st, (const uint8_t*)s.din, g, f, (uint8_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0);
+        else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t, false>), grid, block, 0, s.st, (const uint16_t*)s.din, g, f, (uint16_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0);
+        else hipLaunchKernelGGL((warp_tiled_kernel<float, false>), grid, block, 0, s.st, (const float*)s.din, g, f, (float*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0);
         PG_HIP(hipGetLastError());
         PG_HIP(hipMemcpyAsync(out_host[i], s.dout, nb, hipMemcpyDeviceToHost, s.st));
     }
@@ -536,12 +591,33 @@ int ma_merge_flows_tiled(ma_ctx* ctx, const float* flow1, const float* flow2, in
         const int bands = (2 * overlap + CM_ROWS - 1) / CM_ROWS + (tile - 2 * overlap + CM_ROWS - 1) / CM_ROWS;
         hipLaunchKernelGGL(cell_max_kernel, dim3(nsegx, (g.nty + 1) * bands), dim3(256), 0, ctx->stream,
                            (const float2*)flow1, (const float2*)flow2, g, nsegx, cellkeys);
-        hipLaunchKernelGGL(window_from_cells_kernel, dim3((nwin + 255) / 256), dim3(256), 0, ctx->stream, cellkeys, g,
-                           nsegx, maxes);
+        hipLaunchKernelGGL((window_from_cells_kernel<2>), dim3((nwin + 255) / 256), dim3(256), 0, ctx->stream, cellkeys,
+                           (const unsigned*)nullptr, g, nsegx, maxes);
     } else {
         hipLaunchKernelGGL(window_max_kernel, dim3(nwin, (g.Ph + WM_ROWS - 1) / WM_ROWS), dim3(256), 0, ctx->stream,
                            (const float2*)flow1, (const float2*)flow2, g, maxes);
     }
+    hipLaunchKernelGGL(merge_flows_kernel, dim3((W + 255) / 256, (H + MERGE_ROWS - 1) / MERGE_ROWS), dim3(256), 0, ctx->stream, (const float2*)flow1,
+                       (const float2*)flow2, g, maxes, (float2*)out);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+int ma_merge_flows_tiled_cells(ma_ctx* ctx, const float* flow1, const float* flow2, int H, int W, int tile, int overlap,
+                               const unsigned* cellkeys1, const unsigned* cellkeys2, float* out)
+{
+    MA_REQUIRE(ctx && flow1 && flow2 && out && cellkeys1 && cellkeys2, "NULL argument");
+    MA_REQUIRE(H > 0 && W > 0 && H <= 65535, "bad image size");
+    MA_REQUIRE(tile > 2 * overlap && overlap > 0, "flow cell maxima need tile > 2*overlap > 0");
+    MaTiling g = ma_make_tiling(H, W, tile, overlap);
+    MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
+    MA_HIP(hipSetDevice(ctx->device));
+    const int nwin = g.ntx * g.nty, nsegx = 2 * g.ntx + 1;
+    MA_TRY(ma_dconst_reserve(ctx, (size_t)nwin * 2 * sizeof(unsigned)));
+    unsigned* maxes = (unsigned*)ctx->dconst;
+    MaProfScope ps(ctx, MA_K_MERGE, (double)H * W);
+    hipLaunchKernelGGL((window_from_cells_kernel<1>), dim3((nwin + 255) / 256), dim3(256), 0, ctx->stream, cellkeys1,
+                       cellkeys2, g, nsegx, maxes);
     hipLaunchKernelGGL(merge_flows_kernel, dim3((W + 255) / 256, (H + MERGE_ROWS - 1) / MERGE_ROWS), dim3(256), 0, ctx->stream, (const float2*)flow1,
                        (const float2*)flow2, g, maxes, (float2*)out);
     MA_HIP(hipGetLastError());

@@ -25,7 +25,7 @@ def _dt(dtype):
 class DeviceArray:
     """Dense row-major array living in HBM.  Freed back to the context's pool on `free()`/GC."""
 
-    __slots__ = ("ctx", "shape", "dtype", "ptr", "_nbytes_alloc", "_owner", "minmax")
+    __slots__ = ("ctx", "shape", "dtype", "ptr", "_nbytes_alloc", "_owner", "minmax", "cellkeys")
 
     def __init__(self, ctx, shape, dtype, ptr, nbytes_alloc, owner=True):
         self.ctx, self.shape, self.dtype, self.ptr = ctx, tuple(int(s) for s in shape), np.dtype(dtype), ptr
@@ -33,6 +33,9 @@ class DeviceArray:
         # optional DeviceArray of two floats (min, max of this array), left by the kernel that produced it
         # (Context.warp / pyr_down with minmax=True) for a following dog_u8; arrays are never modified in place
         self.minmax = None
+        # optional (tile, overlap, DeviceArray of keys): per-cell maxima of this FLOW, left by a warp that read it
+        # (Context.warp(flow_cells=True)) for a following merge_flows
+        self.cellkeys = None
 
     @property
     def size(self):
@@ -314,13 +317,23 @@ class Context:
                                            dst.ptr)
         return dst
 
-    def warp(self, img, flow, tile, overlap, minmax=False):
+    def warp(self, img, flow, tile, overlap, minmax=False, flow_cells=False):
         """Warper.warp() (warper.py:37-53).  minmax=True also leaves the output's (min, max) on the device
-        (out.minmax) for a following dog_u8."""
+        (out.minmax) for a following dog_u8; flow_cells=True the per-cell maxima of `flow` (flow.cellkeys) for a
+        following merge_flows (only where the tiling has cells: tile > 2*overlap > 0)."""
         H, W = img.shape
         if flow.shape != (H, W, 2) or flow.dtype != np.float32:
             raise ValueError(f"flow must be float32 of shape {(H, W, 2)}, got {flow.dtype} {flow.shape}")
         out = self.empty((H, W), img.dtype)
+        if flow_cells and tile > 2 * overlap > 0:
+            ncell = (2 * -(-W // tile) + 1) * (2 * -(-H // tile) + 1)
+            keys = self._raw(ncell * 4)
+            if minmax:
+                out.minmax = self.empty((2,), np.float32)
+            self._run(self.lib.ma_warp_tiled_flowcells, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile), int(overlap),
+                      out.ptr, out.minmax.ptr if minmax else None, keys.ptr)
+            flow.cellkeys = (int(tile), int(overlap), keys)
+            return out
         if minmax:
             out.minmax = self.empty((2,), np.float32)
             self._run(self.lib.ma_warp_tiled_minmax, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile),
@@ -360,8 +373,13 @@ class Context:
             raise ValueError("flows must have the same shape")
         H, W = flow1.shape[:2]
         out = self.empty((H, W, 2), np.float32)
-        self._run(self.lib.ma_merge_flows_tiled, flow1.ptr, flow2.ptr, H, W, int(tile), int(overlap),
-                                              out.ptr)
+        k1, k2 = flow1.cellkeys, flow2.cellkeys
+        if k1 is not None and k2 is not None and k1[:2] == k2[:2] == (int(tile), int(overlap)):
+            # both flows went through a warp that folded their cell maxima: no pass over the flows for the .max() tests
+            self._run(self.lib.ma_merge_flows_tiled_cells, flow1.ptr, flow2.ptr, H, W, int(tile), int(overlap),
+                      k1[2].ptr, k2[2].ptr, out.ptr)
+        else:
+            self._run(self.lib.ma_merge_flows_tiled, flow1.ptr, flow2.ptr, H, W, int(tile), int(overlap), out.ptr)
         return out
 
     def pyr_down(self, img, minmax=False):

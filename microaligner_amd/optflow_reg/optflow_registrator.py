@@ -99,7 +99,9 @@ class OptFlowRegistrator:
     def _warp(self, img, flow):
         # same call as Warper.warp() on device arrays; the kernel also leaves the output's min / max on the device,
         # which the dog() of the warped image would otherwise have to reduce in a pass of its own
-        return self._ctx.warp(img, flow, self._warper.tile_size, self._warper.overlap, minmax=True)
+        # ... and the per-cell maxima of the flow it reads, which a following merge of that flow uses for its
+        # per-window flow.max() == 0 tests instead of a pass of its own over both flows
+        return self._ctx.warp(img, flow, self._warper.tile_size, self._warper.overlap, minmax=True, flow_cells=True)
 
     # -- the hot path -----------------------------------------------------------------------
     def register(self):

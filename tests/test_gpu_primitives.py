@@ -193,6 +193,32 @@ def test_merge_flows_nan_window_takes_the_general_branch(ctx, T, ov):
     assert np.array_equal(np.isnan(got), np.isnan(exp))
 
 
+@pytest.mark.parametrize("shape,T,ov", [((330, 310), 100, 15), ((523, 777), 128, 40), ((260, 410), 64, 31), ((90, 80), 100, 20)])
+def test_merge_with_cell_maxima_from_the_warps_matches_the_oracle(ctx, shape, T, ov):
+    """Inside register() both flows of a merge have been read by a warp, which folds their per-cell maxima as a
+    by-product (ma_warp_tiled_flowcells); the merge then takes its per-window .max() tests from those
+    (ma_merge_flows_tiled_cells).  Same bits as the stand-alone merge, shortcuts and NaN windows included."""
+    h, w = shape
+    f1, f2 = rand_flow(h, w, 11, 3.0), rand_flow(h, w, 12, 2.0)
+    f1[: h // 3, : w // 3] = 0                                    # flow1 all zero in some windows
+    f1[h // 2:, : w // 4] = -np.abs(f1[h // 2:, : w // 4])        # max == 0 only through the zero padding
+    f2[h // 2:, w // 2:] = 0
+    f2[3, 5, 1] = np.nan
+    img = np.random.default_rng(1).random((h, w)).astype(np.float32)
+    d1, d2, dimg = ctx.asdevice(f1), ctx.asdevice(f2), ctx.asdevice(img)
+    for f, d in ((f1, d1), (f2, d2)):
+        out = ctx.warp(dimg, d, T, ov, minmax=True, flow_cells=True)
+        assert d.cellkeys is not None and d.cellkeys[:2] == (T, ov)
+        assert np.array_equal(out.numpy(), RO.warp(img, f, T, ov), equal_nan=True)      # the warp itself is unchanged
+        lo, hi = out.minmax.numpy()
+        assert (lo, hi) == (np.nanmin(out.numpy()), np.nanmax(out.numpy())) or np.isnan(out.numpy()).any()
+    got = ctx.merge_flows(d1, d2, T, ov).numpy()
+    exp = RO.merge_flows(f1, f2, T, ov)
+    assert np.array_equal(got, exp, equal_nan=True)
+    # a flow without cell maxima (or with those of another tiling) falls back to the stand-alone reduction
+    assert np.array_equal(ctx.merge_flows(ctx.asdevice(f1), d2, T, ov).numpy(), exp, equal_nan=True)
+
+
 def test_merge_two_flows_function(ctx):
     from microaligner_amd import merge_two_flows
     f1, f2 = rand_flow(90, 80, 6, 2.0), rand_flow(90, 80, 7, 2.0)
