@@ -201,37 +201,23 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
     constexpr int WR = WARP_ROWS;
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * WR;
     const bool xin = x < g.W;
-    if (!MM && !xin) return;
+    if (!MM && !cellkeys && !xin) return;
     float lo = INFINITY, hi = -INFINITY;
+    unsigned ck_row[WARP_ROWS];   // keys of this thread's flow values, row by row (0 = nothing)
+    int ck_sx = -1;               // x segment of this thread's column (-1: outside the image)
+    if (cellkeys) {
+#pragma unroll
+        for (int r = 0; r < WARP_ROWS; r++) ck_row[r] = 0u;
+    }
     if (xin) {
         const int ox = g.T > 0 ? (x / g.T) * g.T - g.ov : 0;
         float2 f[WR];
 #pragma unroll
         for (int r = 0; r < WR; r++) f[r] = flow[(size_t)min(y0 + r, g.H - 1) * g.W + x];
         if (cellkeys) {
-            const int ylast = min(y0 + WR - 1, g.H - 1);
-            const int sy0 = d_segment(y0, g.T, g.ov), sx = d_segment(x, g.T, g.ov);
-            if (sy0 == d_segment(ylast, g.T, g.ov)) {
-                // the block's rows share a y segment: one value per thread, one atomic per wave where the wave's
-                // columns share an x segment too (segments are >= 2*ov wide: the common case)
-                float m = d_max_nan(f[0].x, f[0].y);
 #pragma unroll
-                for (int r = 1; r < WR; r++)
-                    if (y0 + r < g.H) m = d_max_nan(m, d_max_nan(f[r].x, f[r].y));
-                const int sx_first = __shfl(sx, 0), sx_last = __shfl(sx, 63);
-                const bool full = __builtin_amdgcn_readfirstlane(__popcll(__ballot(1))) == 64;
-                if (full && sx_first == sx_last) {
-                    for (int off = 32; off > 0; off >>= 1) m = d_max_nan(m, __shfl_down(m, off));
-                    if ((threadIdx.x & 63) == 0) atomicMax(&cellkeys[(size_t)sy0 * nsegx + sx], f2key(m));
-                } else {
-                    atomicMax(&cellkeys[(size_t)sy0 * nsegx + sx], f2key(m));
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if (y0 + r < g.H)
-                        atomicMax(&cellkeys[(size_t)d_segment(y0 + r, g.T, g.ov) * nsegx + sx], f2key(d_max_nan(f[r].x, f[r].y)));
-            }
+            for (int r = 0; r < WR; r++) ck_row[r] = y0 + r < g.H ? f2key(d_max_nan(f[r].x, f[r].y)) : 0u;
+            ck_sx = d_segment(x, g.T, g.ov);
         }
         T res[WR];
 #pragma unroll
@@ -246,6 +232,28 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
                 out[(size_t)(y0 + r) * g.W + x] = res[r];
                 if (MM) { lo = fminf(lo, (float)res[r]); hi = fmaxf(hi, (float)res[r]); }
             }
+    }
+    if (cellkeys) {
+        // all 64 lanes are here.  One atomic per wave and (x segment, y segment) pair: the lanes of a wave hold 64
+        // consecutive columns, i.e. one x segment, rarely two or three; the block's 8 rows one y segment, rarely two.
+        // (Per-lane atomics on the few hundred cell addresses serialise in L2: 4.5 ms instead of 0.3 per launch.)
+        const int sy_first = d_segment(y0, g.T, g.ov), sy_last = d_segment(min(y0 + WR - 1, g.H - 1), g.T, g.ov);
+        for (int sy = sy_first; sy <= sy_last; sy++) {
+            unsigned k = 0u;
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if (sy_first == sy_last || d_segment(min(y0 + r, g.H - 1), g.T, g.ov) == sy) k = max(k, ck_row[r]);
+            unsigned long long todo = __ballot(ck_sx >= 0);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int seg = __shfl(ck_sx, leader);
+                const bool mine = ck_sx == seg;
+                unsigned v = mine ? k : 0u;
+                for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
+                if ((int)(threadIdx.x & 63) == leader && v) atomicMax(&cellkeys[(size_t)sy * nsegx + seg], v);
+                todo &= ~__ballot(mine);
+            }
+        }
     }
     if (MM) d_block_minmax(lo, hi, part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
 }
