@@ -250,7 +250,12 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
                 const bool mine = ck_sx == seg;
                 unsigned v = mine ? k : 0u;
                 for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
-                if ((int)(threadIdx.x & 63) == leader && v) atomicMax(&cellkeys[(size_t)sy * nsegx + seg], v);
+                // the maximum of a cell settles after a few waves: look before the read-modify-write (a stale value
+                // only costs a redundant atomic, the maximum is monotonic) -- 1250 waves share one cell address
+                if ((int)(threadIdx.x & 63) == leader && v) {
+                    unsigned* cell = &cellkeys[(size_t)sy * nsegx + seg];
+                    if (v > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, v);
+                }
                 todo &= ~__ballot(mine);
             }
         }
