@@ -140,9 +140,11 @@ int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const f
 /* ma_warp_tiled that also leaves by-products on the device for the steps that follow it inside register():
  * minmax_dev (may be NULL): (min, max) of the warped image, which the dog() of that image takes (ma_dog_u8_minmax);
  * flow_cellkeys_dev: maximum of both FLOW components over the (2*ntx+1) x (2*nty+1) cells the window borders
- * k*tile -+ overlap cut the image into (row-major, order-preserving unsigned keys, NaN = largest), from which
+ * k*tile -+ overlap cut the image into (MA_FLOW_CELL_REPLICAS partial copies of the row-major cell array, to be folded
+ * with max; order-preserving unsigned keys, NaN = largest), from which
  * ma_merge_flows_tiled_cells derives the per-window flow.max() tests of merge_two_flows
  * (optflow_registrator.py:38-42) without reading the flows again.  Requires tile > 2*overlap > 0. */
+#define MA_FLOW_CELL_REPLICAS 32
 int ma_warp_tiled_flowcells(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile,
                             int overlap, void* out, float* minmax_dev, unsigned* flow_cellkeys_dev);
 

@@ -185,6 +185,7 @@ __device__ __forceinline__ int d_segment(int v, int T, int ov)
 // WARP_ROWS rows per thread: the flow loads of all rows are issued before the first gather, the gathers of all
 // rows before the first store -- 8 rows in flight per thread run 1.4x faster than one (measured, profiles/r01_notes.md)
 constexpr int WARP_ROWS = 8;
+constexpr int CELL_REPLICAS = 32;   // copies of the flow cell-maxima array (ma_warp_tiled_flowcells)
 // MM: also reduce (min, max) of the block's output pixels into part[2 * block] (input conditioning of a following
 // dog(): the consumer then skips its own pass over the image)
 // cellkeys (may be NULL; needs T > 2*ov > 0): also fold the maximum of both FLOW components over the cells the window
@@ -196,7 +197,7 @@ template <typename T, bool MM>
 __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ img, MaTiling g,
                                                          const float2* __restrict__ flow, T* __restrict__ out,
                                                          float* __restrict__ part, unsigned* __restrict__ cellkeys,
-                                                         int nsegx)
+                                                         int nsegx, int nsegy)
 {
     constexpr int WR = WARP_ROWS;
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = blockIdx.y * WR;
@@ -250,12 +251,10 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
                 const bool mine = ck_sx == seg;
                 unsigned v = mine ? k : 0u;
                 for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, off));
-                // the maximum of a cell settles after a few waves: look before the read-modify-write (a stale value
-                // only costs a redundant atomic, the maximum is monotonic) -- 1250 waves share one cell address
-                if ((int)(threadIdx.x & 63) == leader && v) {
-                    unsigned* cell = &cellkeys[(size_t)sy * nsegx + seg];
-                    if (v > __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(cell, v);
-                }
+                // ~1250 waves share a cell: the atomics go to one of CELL_REPLICAS copies of the cell array, picked by the
+                // block row, so that they spread over L2 channels instead of queueing on one address
+                if ((int)(threadIdx.x & 63) == leader && v)
+                    atomicMax(&cellkeys[((size_t)(blockIdx.y % CELL_REPLICAS) * nsegy + sy) * nsegx + seg], v);
                 todo &= ~__ballot(mine);
             }
         }
@@ -359,7 +358,13 @@ __global__ void window_from_cells_kernel(const unsigned* __restrict__ cellkeys, 
         for (int i = 0; i < 3; i++) {
             const size_t cell = (size_t)(2 * ty + j) * nsegx + 2 * tx + i;
             if (STRIDE == 2) { k1 = max(k1, cellkeys[cell * 2]); k2 = max(k2, cellkeys[cell * 2 + 1]); }
-            else { k1 = max(k1, cellkeys[cell]); k2 = max(k2, cellkeys2[cell]); }
+            else {
+                const size_t ncell = (size_t)nsegx * (2 * g.nty + 1);
+                for (int rep = 0; rep < CELL_REPLICAS; rep++) {
+                    k1 = max(k1, cellkeys[rep * ncell + cell]);
+                    k2 = max(k2, cellkeys2[rep * ncell + cell]);
+                }
+            }
         }
     maxkeys[widx * 2] = k1;
     maxkeys[widx * 2 + 1] = k2;
@@ -490,11 +495,11 @@ static int warp_tiled_impl(ma_ctx* ctx, const void* img, int dtype, int H, int W
     if (flow_cellkeys_dev) MA_REQUIRE(tile > 2 * overlap && overlap > 0, "flow cell maxima need tile > 2*overlap > 0");
     MaProfScope ps(ctx, MA_K_WARP, (double)H * W);
     if (flow_cellkeys_dev)
-        MA_HIP(hipMemsetAsync(flow_cellkeys_dev, 0, (size_t)nsegx * nsegy * sizeof(unsigned), ctx->stream));
+        MA_HIP(hipMemsetAsync(flow_cellkeys_dev, 0, (size_t)CELL_REPLICAS * nsegx * nsegy * sizeof(unsigned), ctx->stream));
     const float2* f = (const float2*)flow;
     unsigned* ck = flow_cellkeys_dev;
-#define MA_WARP(T) do { if (part) hipLaunchKernelGGL((warp_tiled_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part, ck, nsegx); \
-                        else hipLaunchKernelGGL((warp_tiled_kernel<T, false>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part, ck, nsegx); } while (0)
+#define MA_WARP(T) do { if (part) hipLaunchKernelGGL((warp_tiled_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part, ck, nsegx, nsegy); \
+                        else hipLaunchKernelGGL((warp_tiled_kernel<T, false>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part, ck, nsegx, nsegy); } while (0)
     if (dtype == MA_U8) MA_WARP(uint8_t);
     else if (dtype == MA_U16) MA_WARP(uint16_t);
     else MA_WARP(float);
@@ -570,9 +575,9 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
     for (int i = 0; i < n_pages; i++) {
         Slot& s = slots[i % ns];  // stream order keeps the slot's buffers safe: copy-in waits for the previous copy-out
         PG_HIP(hipMemcpyAsync(s.din, pages_host[i], nb, hipMemcpyHostToDevice, s.st));
-        if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t, false>), grid, block, 0, s.st, (const uint8_t*)s.din, g, f, (uint8_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0);
-        else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t, false>), grid, block, 0, s.st, (const uint16_t*)s.din, g, f, (uint16_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0);
-        else hipLaunchKernelGGL((warp_tiled_kernel<float, false>), grid, block, 0, s.st, (const float*)s.din, g, f, (float*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0);
+        if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t, false>), grid, block, 0, s.st, (const uint8_t*)s.din, g, f, (uint8_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0, 0);
+        else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t, false>), grid, block, 0, s.st, (const uint16_t*)s.din, g, f, (uint16_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0, 0);
+        else hipLaunchKernelGGL((warp_tiled_kernel<float, false>), grid, block, 0, s.st, (const float*)s.din, g, f, (float*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0, 0);
         PG_HIP(hipGetLastError());
         PG_HIP(hipMemcpyAsync(out_host[i], s.dout, nb, hipMemcpyDeviceToHost, s.st));
     }

@@ -327,7 +327,7 @@ class Context:
         out = self.empty((H, W), img.dtype)
         if flow_cells and tile > 2 * overlap > 0:
             ncell = (2 * -(-W // tile) + 1) * (2 * -(-H // tile) + 1)
-            keys = self._raw(ncell * 4)
+            keys = self._raw(L.MA_FLOW_CELL_REPLICAS * ncell * 4)
             if minmax:
                 out.minmax = self.empty((2,), np.float32)
             self._run(self.lib.ma_warp_tiled_flowcells, img.ptr, _dt(img.dtype), H, W, flow.ptr, int(tile), int(overlap),
