@@ -138,3 +138,16 @@ def test_cfg5_mosaic_tiles_affine_init_then_optical_flow_refine():
     exp_flow, _ = RO.register(ref, affine, nthreads=CORES, **of_params)
     assert np.array_equal(out[0][2], exp_flow)
     assert np.array_equal(out[0][0], RO.warp(affine, exp_flow, 1000, 100))
+
+
+@pytest.mark.parametrize("shape,dtype,params", [
+    ((2311, 1789), np.float32, dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True)),     # ragged: 311 / 789 px valid in the last windows
+    ((1999, 3005), np.uint8, dict(num_pyr_lvl=3, use_full_res_img=False, use_dog=True)),      # final pyrUp to odd sizes (Q2)
+    ((1203, 1201), np.uint16, dict(num_pyr_lvl=1, use_full_res_img=True, use_dog=False, num_iterations=2)),  # 2 x 2 windows with 203 / 201 px valid
+])
+def test_ragged_shapes_at_the_default_tile_size_equal_the_oracle(shape, dtype, params):
+    """Default tile 1000 / overlap 100 / window 99 on shapes that are not multiples of anything: border windows with
+    a sliver of valid pixels (active and needed extents), partial strips and segments of the fused DOG, odd pyramid
+    sizes."""
+    ref, mov = synthetic.make_pair(*shape, seed=31, dtype=dtype)
+    _compare(ref, mov, params, f"ragged {shape} {np.dtype(dtype).name}")
