@@ -24,7 +24,7 @@ GROUP = {"fb_polyexp_m0": "polyexp_m0", "fb_blur_v": "blur_v", "fb_blur_h_solve"
          "pyr_down_kernel": "pyr_down", "pyr_up_flow_kernel": "pyr_up", "dog_rows": "dog", "dog_cols_diff": "dog",
          "dog_fused": "dog",
          "scale_to_u8": "dog", "minmax_partial": "dog", "minmax_final": "dog", "dog_params_in": "dog",
-         "dog_params_out": "dog", "joint_hist_kernel": "nmi", "nmi_reduce_kernel": "nmi"}
+         "dog_params_out": "dog", "joint_hist_kernel": "nmi", "joint_hist16_kernel": "nmi", "nmi_reduce_kernel": "nmi"}
 
 def newest(pattern):
     """gpurun merges new files next to those of earlier calls: take the most recent match."""
