@@ -2,12 +2,15 @@
 (microaligner/feature_reg/feature_registrator.py:35-312): same attributes and defaults, register() returns the
 2x3 float64 matrix that maps the moving image onto the reference.
 
-Division of labour: the dense steps -- pyramid (cv2.pyrDown), dog(), the image transforms
-(cv2.warpAffine up to 32000 px, scikit-image's warp above) and the mutual-information gate -- are HIP kernels behind
-the C-ABI; the sparse steps (FAST, DAISY, matching, RANSAC) run on the host (feature_detection.py / sparse_cpu.py).
+Division of labour: pyramid (cv2.pyrDown), dog(), the image transforms (cv2.warpAffine up to
+32000 px, scikit-image's warp above), the mutual-information gate, the FAST score map, the DAISY descriptors and the
+2-NN search are HIP kernels behind the C-ABI; picking corners, the ratio test and RANSAC (a few thousand points) run
+on the host (feature_detection.py / sparse_cpu.py).  The public surface mirrors the reference; the machinery below it
+is this package's own: one `_Level` record per pyramid level, one `_register_level` pass per level.
 """
 import gc
-from typing import List, Tuple, Union
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
 
 import numpy as np
 
@@ -17,6 +20,14 @@ from ..shared_modules.similarity_scoring import check_if_higher_similarity
 from . import affine_math
 from .feature_detection import Features
 from .tile_registration import find_features, register_img_pair
+
+
+@dataclass
+class _Level:
+    """One pyramid level of the reference image: subsampling factor, the level (device), its features."""
+    factor: int
+    image: DeviceArray
+    features: Optional[Features] = None
 
 
 class FeatureRegistrator:
@@ -29,10 +40,7 @@ class FeatureRegistrator:
         self.use_full_res_img = False
         self.use_dog = True
         self.verbose = True      # addition: the reference prints unconditionally
-        self._ref_pyr_features: List[Features] = []
-        self._ref_img_pyr: list = []
-        self._factors = [8, 4, 2]
-        self._this_pyr_factor = 1
+        self._levels: List[_Level] = []   # reference side, coarsest first; kept for register(reuse_ref_img=True)
 
     # -- inputs ---------------------------------------------------------------------------------------------
     @property
@@ -57,42 +65,44 @@ class FeatureRegistrator:
         if self.verbose:
             print(*args)
 
+    @property
+    def level_factors(self) -> List[int]:
+        """Subsampling factors of the levels register() will visit (coarsest first), e.g. [8, 4, 2]."""
+        return [f for f, _ in self._pyramid_plan(np.shape(self._ref_img))] if np.size(self._ref_img) else [8, 4, 2]
+
     # -- registration ---------------------------------------------------------------------------------------
     def calc_ref_img_features(self):
         """:70-76: pyramid of the reference image and the features of every level."""
-        self._ref_img_pyr, self._factors = self._generate_img_pyr(self._ref_img)
-        self._ref_pyr_features = [find_features(self._host(self.dog(lvl, self.use_dog)), self.tile_size, get_context())
-                                  for lvl in self._ref_img_pyr]
+        self._levels = [_Level(factor, img) for factor, img in self._build_pyramid(self._ref_img)]
+        for lvl in self._levels:
+            lvl.features = self._features_of(lvl.image)
 
     def register(self, reuse_ref_img: bool = False) -> np.ndarray:
-        """:78-119: coarse-to-fine; every level aligns the moving level (pre-transformed by what the coarser
-        levels found) in `num_iterations` rounds and contributes one matrix, rescaled to full resolution."""
+        """:78-119: coarse-to-fine.  Every level sees the moving level pre-transformed by what the coarser levels
+        found (their matrices brought to this level's pixel size), refines it in `num_iterations` gated rounds and
+        contributes one matrix; the result is the product of the per-level matrices at full resolution."""
         check_img_is_provided(self._ref_img, "ref")
         check_img_is_provided(self._mov_img, "mov")
         check_img_dims_match(self._ref_img, self._mov_img)
-        if not reuse_ref_img or self._ref_pyr_features == []:
+        if not (reuse_ref_img and self._levels):
             self.calc_ref_img_features()
-        mov_img_pyrs, _ = self._generate_img_pyr(self._mov_img)
-
-        fullscale_t_mat_list = []
-        for i, factor in enumerate(self._factors):
+        moving = self._build_pyramid(self._mov_img)
+        found: List[np.ndarray] = []            # one matrix per finished level, in full-resolution pixels
+        for ref_level, (factor, mov_level) in zip(self._levels, moving):
             self._log("Pyramid factor", factor)
-            self._this_pyr_factor = factor
-            mov_lvl = mov_img_pyrs[i]
-            if i > 0:
-                rescaled = [self._rescale_t_mat(m, 1 / factor) for m in fullscale_t_mat_list]
-                mov_lvl = self.transform_img(mov_lvl, self._multiply_transform_matrices(rescaled))
-            _, t_mat = self._iterative_alignment(self._ref_img_pyr[i], self._ref_pyr_features[i], mov_lvl)
-            fullscale_t_mat_list.append(self._rescale_t_mat(t_mat, factor))
+            if found:
+                so_far = affine_math.compose([affine_math.with_translation_scaled(m, 1 / factor) for m in found])
+                mov_level = self.transform_img(mov_level, so_far)
+            level_mat = self._register_level(ref_level, mov_level)
+            found.append(affine_math.with_translation_scaled(level_mat, factor))
             gc.collect()
-        return self._multiply_transform_matrices(fullscale_t_mat_list)
+        return affine_math.compose(found)
 
     # -- image transforms -----------------------------------------------------------------------------------
     def transform_big_img(self, img, t_mat):
         """:121-126: skimage.transform.warp(img, AffineTransform(pinv(M)), preserve_range=True).astype(dtype)."""
         ctx = get_context()
-        inv = np.linalg.pinv(np.append(np.asarray(t_mat, np.float64), [[0, 0, 1]], axis=0))
-        out = ctx.warp_affine(ctx.asdevice(img), inv)
+        out = ctx.warp_affine(ctx.asdevice(img), np.linalg.pinv(affine_math.homogeneous(t_mat)))
         return out if isinstance(img, DeviceArray) else out.numpy()
 
     def transform_img(self, img, t_mat):
@@ -103,79 +113,71 @@ class FeatureRegistrator:
         out = ctx.warp_affine_cv(ctx.asdevice(img), t_mat)
         return out if isinstance(img, DeviceArray) else out.numpy()
 
-    def _generate_img_pyr(self, arr) -> Tuple[list, List[int]]:
-        """:134-160: levels from the smallest to the largest, each kept on the device."""
+    # -- pyramid --------------------------------------------------------------------------------------------
+    def _pyramid_plan(self, shape) -> List[Tuple[int, int]]:
+        """[(factor, number of pyrDown steps)] coarsest first (:134-160): factors 2, 4, ... while both sides keep at
+        least 100 px, at most num_pyr_lvl of them, plus the image itself if use_full_res_img."""
         if self.num_pyr_lvl < 0:
             raise ValueError("Number of pyramid levels cannot be less than 1")
         if self.num_pyr_lvl == 0 and not self.use_full_res_img:
             raise ValueError("Number of pyramid levels is 0 and use_full_res_img is False. "
                              "Please change one of the parameters")
+        plan = []
+        for steps in range(1, self.num_pyr_lvl + 1):
+            if min(shape[0], shape[1]) / 2 ** steps < 100:
+                break
+            plan.append((2 ** steps, steps))
+        plan.reverse()
+        if self.use_full_res_img:
+            plan.append((1, 0))
+        return plan
+
+    def _build_pyramid(self, arr) -> List[Tuple[int, DeviceArray]]:
+        """[(factor, level on the device)] following _pyramid_plan; every level is pyrDown of the next finer one."""
         ctx = get_context()
         full = ctx.asdevice(arr)
-        pyramid, factors, cur = [], [], full
-        for lvl in range(self.num_pyr_lvl):
-            factor = 2 ** (lvl + 1)
-            if full.shape[0] / factor < 100 or full.shape[1] / factor < 100:
-                break
-            cur = ctx.pyr_down(cur)
-            pyramid.append(cur)
-            factors.append(factor)
-        pyramid.reverse()
-        factors.reverse()
-        if self.use_full_res_img:
-            pyramid.append(full)
-            factors.append(1)
-        return pyramid, factors
+        plan = self._pyramid_plan(full.shape)
+        by_steps, cur = {0: full}, full
+        for steps in range(1, max((n for _, n in plan), default=0) + 1):
+            cur = by_steps[steps] = ctx.pyr_down(cur)
+        return [(factor, by_steps[steps]) for factor, steps in plan]
 
-    # -- one level -------------------------------------------------------------------------------------------------
-    def _iterative_alignment(self, ref_img, ref_features: Features, mov_img):
-        """:162-193: estimate, gate on mutual information and plausibility, accumulate."""
+    # -- one level ------------------------------------------------------------------------------------------
+    def _features_of(self, img) -> Features:
+        """Features of dog(img) (or of img itself with use_dog off): tiles cut on the host, dense work on the device."""
+        pre = self.dog(img, self.use_dog)
+        host = pre.numpy() if isinstance(pre, DeviceArray) else np.asarray(pre)
+        return find_features(host, self.tile_size, get_context())
+
+    def _register_level(self, ref_level: _Level, mov_level) -> np.ndarray:
+        """:162-207: `num_iterations` rounds on one level.  A round estimates the similarity that maps the current
+        image onto the reference features; it is kept only if the mutual-information gate prefers the transformed
+        image and the matrix is plausible (affine_math), otherwise the round contributes the identity.  After a kept
+        round the ORIGINAL level is transformed by the product of the kept matrices (no resampling chain)."""
         if self.num_iterations < 1:
             raise ValueError("Number of iterations cannot be less than 1")
-        t_matrices = []
-        aligned_img = mov_img
-        ref_dog = self.dog(ref_img, True)
-        for i in range(self.num_iterations):
-            self._log("    Iteration", i + 1, "/", self.num_iterations)
-            mov_img_aligned, est_t_mat_pyr = self._align_imgs(ref_features, aligned_img)
-            is_more_similar = check_if_higher_similarity(ref_dog, self.dog(mov_img_aligned, True),
-                                                         self.dog(aligned_img, True), self.tile_size, self.verbose)
-            is_valid_transform = self._check_if_valid_transform(est_t_mat_pyr, mov_img.shape)
-            if any(is_more_similar) and is_valid_transform:
+        ctx = get_context()
+        ref_gate = self.dog(ref_level.image, True)
+        rounds: List[np.ndarray] = []
+        current = mov_level
+        for it in range(self.num_iterations):
+            self._log("    Iteration", it + 1, "/", self.num_iterations)
+            # the exact 2-NN search over up to 45 000 x 45 000 descriptors runs on the device (ma_knn2_l2)
+            estimate = register_img_pair(ref_level.features, self._features_of(current), self.verbose, knn=ctx.knn2)
+            is_identity = bool(np.array_equal(estimate, affine_math.IDENTITY))
+            candidate = current if is_identity else self.transform_img(current, estimate)
+            improved = check_if_higher_similarity(ref_gate, self.dog(candidate, True), self.dog(current, True),
+                                                  self.tile_size, self.verbose)
+            plausible = (affine_math.centre_stays_inside(estimate, mov_level.shape)
+                         and affine_math.scales_plausible(estimate))
+            if any(improved) and plausible:
                 self._log("    Better alignment than before")
-                t_matrices.append(est_t_mat_pyr)
-                aligned_img = self._realign_img(mov_img, t_matrices)
+                rounds.append(estimate)
+                current = self.transform_img(mov_level, affine_math.compose(rounds))
             else:
                 self._log("    Worse alignment than before")
-                t_matrices.append(np.eye(2, 3))
-        return aligned_img, self._multiply_transform_matrices(t_matrices)
-
-    def _align_imgs(self, ref: Union[np.ndarray, DeviceArray, Features], mov_img):
-        """:195-207."""
-        if isinstance(ref, Features):
-            ref_features = ref
-        else:
-            ref_features = find_features(self._host(self.dog(ref, self.use_dog)), self.tile_size, get_context())
-        mov_features = find_features(self._host(self.dog(mov_img, self.use_dog)), self.tile_size, get_context())
-        # the exact 2-NN search over up to 45 000 x 45 000 descriptors runs on the device (ma_knn2_l2)
-        transform_mat = register_img_pair(ref_features, mov_features, self.verbose, knn=get_context().knn2)
-        if np.equal(transform_mat, np.eye(2, 3)).all():
-            return mov_img, np.eye(2, 3)
-        return self.transform_img(mov_img, transform_mat), transform_mat
-
-    def _realign_img(self, mov_img, mat_list):
-        return self.transform_img(mov_img, self._multiply_transform_matrices(mat_list))
-
-    # -- matrix bookkeeping (feature_reg/affine_math.py) ---------------------------------------------------------
-    def _multiply_transform_matrices(self, mat_list):
-        return affine_math.compose(mat_list)
-
-    def _rescale_t_mat(self, t_mat, scale: float):
-        return affine_math.with_translation_scaled(t_mat, scale)
-
-    def _check_if_valid_transform(self, t_mat, img_shape) -> bool:
-        """Gate of :224-279: the image centre stays inside the image and neither axis is scaled outside [0.3, 3]."""
-        return affine_math.centre_stays_inside(t_mat, img_shape) and affine_math.scales_plausible(t_mat)
+                rounds.append(affine_math.IDENTITY.copy())
+        return affine_math.compose(rounds)
 
     def get_dog_sigmas(self, pyr_factor: int) -> Tuple[int, int]:
         if pyr_factor > 16:
@@ -192,7 +194,3 @@ class FeatureRegistrator:
         if src_max_is_zero:
             return img
         return out if isinstance(img, DeviceArray) else out.numpy()
-
-    @staticmethod
-    def _host(img):
-        return img.numpy() if isinstance(img, DeviceArray) else np.asarray(img)

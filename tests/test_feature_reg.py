@@ -186,8 +186,9 @@ def test_feature_registrator_recovers_a_similarity_transform():
     freg = FeatureRegistrator()
     freg.verbose = False
     freg.num_pyr_lvl, freg.tile_size = 2, 500
-    assert freg._factors == [8, 4, 2] and freg.num_iterations == 3 and freg.use_dog is True
+    assert freg.num_iterations == 3 and freg.use_dog is True
     freg.ref_img, freg.mov_img = ref, mov
+    assert freg.level_factors == [4, 2]
     T = freg.register()
     assert T.shape == (2, 3) and T.dtype == np.float64
     Mi = np.linalg.inv(np.vstack([M, [0, 0, 1]]))[:2]
@@ -198,10 +199,10 @@ def test_feature_registrator_recovers_a_similarity_transform():
     after = np.abs(aligned[inner].astype(np.float64) - ref[inner]).mean()
     assert after < 0.35 * before
     # reuse_ref_img keeps the reference features (the pipeline registers many cycles against one reference)
-    feats = freg._ref_pyr_features
+    feats = [lvl.features for lvl in freg._levels]
     freg.mov_img = mov
     T2 = freg.register(reuse_ref_img=True)
-    assert freg._ref_pyr_features is feats and np.allclose(T2, T)
+    assert all(lvl.features is f0 for lvl, f0 in zip(freg._levels, feats)) and np.allclose(T2, T)
 
 
 @pytest.mark.gpu
@@ -209,15 +210,19 @@ def test_feature_registrator_helpers():
     from microaligner_amd import FeatureRegistrator
     f = FeatureRegistrator()
     a, b = np.array([[1.0, 0, 5], [0, 1, -2]]), np.array([[0.0, -1, 0], [1, 0, 3]])
-    assert np.allclose(f._multiply_transform_matrices([a, b]), (np.vstack([a, [0, 0, 1]]) @ np.vstack([b, [0, 0, 1]]))[:2])
-    assert np.array_equal(f._rescale_t_mat(a, 4), np.array([[1.0, 0, 20], [0, 1, -8]]))
     from microaligner_amd.feature_reg import affine_math as am
+    assert np.allclose(am.compose([a, b]), (np.vstack([a, [0, 0, 1]]) @ np.vstack([b, [0, 0, 1]]))[:2])
+    assert np.array_equal(am.with_translation_scaled(a, 4), np.array([[1.0, 0, 20], [0, 1, -8]]))
     assert am.scales_plausible(a) and not am.scales_plausible(a * np.array([[5, 5, 1]] * 2))
     assert not am.scales_plausible(np.zeros((2, 3)))
     assert am.scales_plausible(np.array([[0.0, 1.0, 0], [0.0, 2.0, 0]])) is False      # rank 1: zero area
     assert am.axis_scales(np.array([[0.0, -2.0, 3], [2.0, 0.0, 1]])) == (2.0, 2.0)     # rotation by 90 deg x 2
     assert am.centre_stays_inside(a, (100, 100)) and not am.centre_stays_inside(np.array([[1.0, 0, 500], [0, 1, 0]]), (100, 100))
-    assert f._check_if_valid_transform(a, (100, 100))
+    assert f.level_factors == [8, 4, 2]
+    f.num_pyr_lvl, f.use_full_res_img = 1, True
+    f.ref_img = np.zeros((300, 500), np.uint8)
+    assert f.level_factors == [2, 1]
+    f.num_pyr_lvl, f.use_full_res_img = 3, False
     with pytest.raises(ValueError):
         f.ref_img = np.zeros((3, 3, 3))
     f.num_pyr_lvl = 0
