@@ -373,6 +373,108 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v(FbGeom g, int m, 
     }
 }
 
+// K2, streaming form (used when the tap pairs are whole groups of R/2, i.e. at the reference's window of 99): one block
+// walks DOWN a 64-column strip of one plane.  The strip's rows live in an LDS ring of C = NW*R + 2m + 4 rows (plus the
+// mirror rows d_sym_fir_ring_pk needs); per chunk of NW*R output rows only the NW*R new rows are staged -- the tiled
+// form above stages all C rows for every chunk, 2.8 x the output -- and their global loads are issued before the
+// filter of the previous chunk runs (R registers per lane), so the memory latency hides behind the arithmetic.
+template <int R, int NW, bool FUSED>
+__global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v_stream(FbGeom g, int m, const float* __restrict__ taps,
+                                                            float* __restrict__ ws, int nplanes, int reach)
+{
+    extern __shared__ float lds[];  // [C + MIR][64]
+    constexpr int H = R / 2, G = 2, CH = NW * R, MIR = 3 * H + 1;
+    const int C = CH + 2 * m + 2 * G;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Ph = g.t.Ph, Pw = g.t.Pw;
+    const int nbx = (Pw + 63) / 64;
+    const int nslots = (int)(((nplanes + 7) / 8) * 8);
+    const int item = d_xcd_work_item(blockIdx.x, nbx * nslots);
+    const int bx = item % nbx;
+    const int bz = d_xcd_unit(item / nbx, nplanes);
+    if (bz >= nplanes) return;
+    const int wl = bz / 5, ch = bz - wl * 5;
+    const float* src = plane_ptr(ws, g, wl, PL_M + ch);
+    float* dst = plane_ptr(ws, g, wl, PL_V + ch);
+    int oy, ox, ey, ex;
+    window_origin(g.t, g.tile0 + wl, oy, ox);
+    window_extent(g, oy, ox, ey, ex);
+    const FbRect need = needed_rect_v(g.t, oy, ox, reach, m);
+    const int x0 = (need.x0 & ~(NEED_XALIGN - 1)) + bx * 64;
+    const int yend = min(ey, need.y1);
+    if (x0 >= min(ex, need.x1) || need.y0 >= yend) return;
+    const int ybase = need.y0 - m - G;       // window row held by virtual row 0 of the walk
+    const int xc = min(x0 + lane, Pw - 1);
+    const bool xin = xc < ex;
+    const unsigned xo = (unsigned)xc * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0,
+                                                                           (int)(g.plane * sizeof(float)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(g.plane * sizeof(float)), 0x00020000);
+    auto load_row = [&](int v) -> float {    // virtual row v = window row ybase + v, replicated at the window border
+        const int y = d_clamp(ybase + v, 0, Ph - 1);
+        float val = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xo, min(y, ey - 1) * g.pitch * 4, 0));
+        if (y >= ey || !xin) val = 0.f;      // beyond the active extent M is exactly zero (and was not written)
+        return val;
+    };
+    auto commit_row = [&](int pos, float val) {   // pos: ring row, 0 <= pos < C
+        lds[pos * 64 + lane] = val;
+        if (pos < MIR) lds[(pos + C) * 64 + lane] = val;
+    };
+    // prologue: virtual rows [0, 2m + 2G) sit at ring rows of the same number
+    {
+        const int npro = 2 * m + 2 * G;
+        constexpr int SB = 13;
+        for (int j0 = w; j0 < npro; j0 += NW * SB) {
+            float v[SB];
+#pragma unroll
+            for (int k = 0; k < SB; k++) v[k] = load_row(min(j0 + NW * k, npro - 1));
+#pragma unroll
+            for (int k = 0; k < SB; k++)
+                if (j0 + NW * k < npro) commit_row(j0 + NW * k, v[k]);
+        }
+    }
+    float nv[R];                              // the NW*R new rows of the coming chunk, R per wave
+    int vnew = 2 * m + 2 * G;                 // first virtual row of those
+    int pnew = vnew;                          // its ring row (C > 2m + 2G)
+    int jbase = m + G;                        // ring row of the chunk's first output row
+#pragma unroll
+    for (int k = 0; k < R; k++) nv[k] = load_row(vnew + w + NW * k);
+    const int x = x0 + lane;
+    for (int y0 = need.y0; y0 < yend; y0 += CH) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            int p = pnew + w + NW * k;
+            if (p >= C) p -= C;
+            commit_row(p, nv[k]);
+        }
+        __syncthreads();
+        vnew += CH;
+        pnew += CH;
+        if (pnew >= C) pnew -= C;
+        if (y0 + CH < yend) {
+#pragma unroll
+            for (int k = 0; k < R; k++) nv[k] = load_row(vnew + w + NW * k);
+        }
+        if (y0 + w * R < yend) {              // else: this wave's rows of the last chunk are not needed
+            int jb = jbase + w * R;
+            if (jb >= C) jb -= C;
+            float acc[R];
+            d_sym_fir_ring_pk<R, FUSED>(lds + lane, jb, C, m, taps, acc);
+            if (x >= need.x0 && x < need.x1) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int y = y0 + w * R + r;
+                    if (y < need.y1) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), drsrc, x * 4, y * g.pitch * 4, 0);
+                }
+            }
+        }
+        jbase += CH;
+        if (jbase >= C) jbase -= C;
+        __syncthreads();                      // every wave is done with the rows the next commit overwrites
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K3: horizontal window blur of V (5 planes) + 2x2 solve (double) + UpdateMatrices / final store.
 // Lanes run along y (one row each) so the register window slides along x; results are transposed
@@ -745,9 +847,17 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
         if (fast) {
             {
                 MaProfScope ps(ctx, MA_K_BLUR_V, px_v[it]);
+                static const int exp_stream = getenv("MA_BV_STREAM") ? atoi(getenv("MA_BV_STREAM")) : 1;  // EXPERIMENT
+                const size_t lds_vs = (size_t)(BV_NW * BV_R + 2 * m + 4 + 3 * (BV_R / 2) + 1) * 64 * sizeof(float);
+                if (exp_stream && m % (BV_R / 2) == 0 && lds_vs <= LDS_MAX) {
+                    const long long items = (long long)((Pw + 63) / 64) * ma_xcd_slots(nwin * 5);
+                    hipLaunchKernelGGL((fb_blur_v_stream<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_vs,
+                                       ctx->stream, g, m, taps, ws, nwin * 5, reach);
+                } else {
                 const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * ma_xcd_slots(nwin * 5);
                 hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_v,
                                    ctx->stream, g, m, taps, ws, nwin * 5, reach);
+                }
             }
             {
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px_h[it]);

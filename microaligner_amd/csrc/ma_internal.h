@@ -275,6 +275,48 @@ __device__ __forceinline__ void d_sym_fir_slide_pk(const float* __restrict__ col
     }
 }
 
+// d_sym_fir_slide_pk over a RING of C rows (ST64 layout: row stride 64 floats) whose first 3*H + 1 rows are mirrored
+// behind row C - 1: element j of the line is at ring row j mod C, and any run of up to 3*H + 1 consecutive elements
+// that starts inside the ring is contiguous in LDS (it may run into the mirror).  jb: ring row of the first output,
+// 0 <= jb < C, wave-uniform.  Requires m % H == 0.  Same operations in the same order as the linear form.
+template <int R, bool FUSED>
+__device__ __forceinline__ void d_sym_fir_ring_pk(const float* __restrict__ col, const int jb, const int C, const int m,
+                                                  const float* __restrict__ taps, float acc[R])
+{
+    static_assert(R % 2 == 0, "R must be even");
+    constexpr int H = R / 2;
+    auto W2 = [&](int o) {
+        int i = jb + o;
+        if (i < 0) i += C;
+        return (ma_f2){col[i * 64], col[(i + H) * 64]};
+    };
+    ma_f2 A[H], P[H], Q[H];
+    const float k0 = taps[0];
+#pragma unroll
+    for (int r = 0; r < H; r++) A[r] = W2(r) * (ma_f2){k0, k0};
+#pragma unroll
+    for (int o = 1; o <= H; o++) P[o % H] = W2(o);
+#pragma unroll
+    for (int o = -1; o <= H - 2; o++) Q[(o + H) % H] = W2(o);
+    const unsigned base = (unsigned)(size_t)col;
+    int rowP = jb, rowQ = jb - H - 1;
+    if (rowQ < 0) rowQ += C;
+    const int full = m / H;
+    for (int g = 0; g < full; g++) {
+        float kg[H];
+#pragma unroll
+        for (int j = 0; j < H; j++) kg[j] = MA_TAP(taps, g * H + 1 + j);
+        d_fir_group_pk<H, FUSED, true>(A, P, Q, kg, base + (unsigned)rowP * 256u, base + (unsigned)rowQ * 256u,
+                                       std::make_integer_sequence<int, H>{});
+        rowP += H;
+        if (rowP >= C) rowP -= C;
+        rowQ -= H;
+        if (rowQ < 0) rowQ += C;
+    }
+#pragma unroll
+    for (int r = 0; r < H; r++) { acc[r] = A[r].x; acc[r + H] = A[r].y; }
+}
+
 // Block-wide (min, max) of per-thread values -> part[0], part[1] (thread 0 writes).  All threads of the block must
 // call it; blocks of up to 1024 threads.
 __device__ __forceinline__ void d_block_minmax(float lo, float hi, float* part)
