@@ -18,7 +18,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cfloat>
-#include <cstdlib>
 
 namespace {
 
@@ -802,6 +801,8 @@ void make_window_taps(int winsize, std::vector<float>& k)
 
 constexpr int BV_R = 14, BV_NW = 4;   // fb_blur_v: 64 columns x (NW*R) = 56 rows per block: at the default window (99 taps) the
                                       // 49 tap pairs are 7 full groups of R/2 and the strip (158 rows) lets 4 blocks share a CU
+constexpr int BVS_NW = 8;             // fb_blur_v_stream: chunks of 8 x 14 = 112 rows, ring of 214 + 22 rows = 60 KB, 2 blocks / CU
+                                      // (measured per launch: 4 waves 1.55 ms, 6 waves 1.70, 8 waves 1.53, 16 waves 1.84; tiled form 1.67)
 constexpr int BH_R = 8, BH_NW = 8;    // fb_blur_h_solve: 64 rows x 64 columns per block
 constexpr size_t LDS_MAX = 160 * 1024;
 
@@ -847,16 +848,16 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
         if (fast) {
             {
                 MaProfScope ps(ctx, MA_K_BLUR_V, px_v[it]);
-                static const int exp_stream = getenv("MA_BV_STREAM") ? atoi(getenv("MA_BV_STREAM")) : 1;  // EXPERIMENT
-                const size_t lds_vs = (size_t)(BV_NW * BV_R + 2 * m + 4 + 3 * (BV_R / 2) + 1) * 64 * sizeof(float);
-                if (exp_stream && m % (BV_R / 2) == 0 && lds_vs <= LDS_MAX) {
+                // the streaming form needs whole tap groups (m % (R/2) == 0: the reference's window of 99) and its ring in LDS
+                const size_t lds_vs = (size_t)(BVS_NW * BV_R + 2 * m + 4 + 3 * (BV_R / 2) + 1) * 64 * sizeof(float);
+                if (m % (BV_R / 2) == 0 && lds_vs <= LDS_MAX) {
                     const long long items = (long long)((Pw + 63) / 64) * ma_xcd_slots(nwin * 5);
-                    hipLaunchKernelGGL((fb_blur_v_stream<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_vs,
-                                       ctx->stream, g, m, taps, ws, nwin * 5, reach);
+                    hipLaunchKernelGGL((fb_blur_v_stream<BV_R, BVS_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BVS_NW),
+                                       lds_vs, ctx->stream, g, m, taps, ws, nwin * 5, reach);
                 } else {
-                const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * ma_xcd_slots(nwin * 5);
-                hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_v,
-                                   ctx->stream, g, m, taps, ws, nwin * 5, reach);
+                    const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * ma_xcd_slots(nwin * 5);
+                    hipLaunchKernelGGL((fb_blur_v<BV_R, BV_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BV_NW), lds_v,
+                                       ctx->stream, g, m, taps, ws, nwin * 5, reach);
                 }
             }
             {
