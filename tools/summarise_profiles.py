@@ -18,7 +18,7 @@ def short(name):
     return m.group(1) if m else name.split("(")[0][:40]
 
 
-GROUP = {"fb_polyexp_m0": "polyexp_m0", "fb_blur_v": "blur_v", "fb_blur_h_solve": "blur_h_solve",
+GROUP = {"fb_polyexp_m0": "polyexp_m0", "fb_blur_v": "blur_v", "fb_blur_v_stream": "blur_v", "fb_blur_h_solve": "blur_h_solve",
          "warp_tiled_kernel": "warp", "window_max_kernel": "merge", "cell_max_kernel": "merge",
          "window_from_cells_kernel": "merge", "merge_flows_kernel": "merge",
          "pyr_down_kernel": "pyr_down", "pyr_up_flow_kernel": "pyr_up", "dog_rows": "dog", "dog_cols_diff": "dog",
