@@ -72,3 +72,38 @@ def test_null_arguments_are_rejected_without_a_device():
     assert b"invalid argument" in lib.ma_last_error()
     with pytest.raises(ValueError):
         _lib.check(_lib.MA_EINVAL)
+
+
+def test_the_product_never_reaches_for_the_oracle():
+    """oracle/ is test infrastructure: nothing under microaligner_amd/ (Python or HIP) may import, load or mention it,
+    and bench.py may only do so inside its cpu_baseline leg."""
+    import ast
+    pkg = os.path.join(ROOT, "microaligner_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                tree = ast.parse(open(path).read())
+                for node in ast.walk(tree):
+                    mods = []
+                    if isinstance(node, ast.Import):
+                        mods = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        mods = [node.module or ""]
+                    assert not any(m == "oracle" or m.startswith("oracle.") for m in mods), path
+                assert "libma_oracle" not in open(path).read(), path
+    bench = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in ast.walk(bench):
+        if isinstance(node, ast.FunctionDef):
+            uses = [n for n in ast.walk(node) if isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle")]
+            assert not uses or node.name == "cpu_baseline", node.name
+    top = [n for n in bench.body if isinstance(n, (ast.Import, ast.ImportFrom))]
+    assert not any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in top)
+
+
+def test_a_missing_library_is_an_import_error(monkeypatch, tmp_path):
+    from microaligner_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libmicroaligner_hip.so"))
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
