@@ -265,7 +265,11 @@ def launch_ranks(n, argv):
         if pending:
             time.sleep(0.05)
     out = procs[0].stdout.read().decode()
-    sys.stdout.write(out)
+    json_lines = [line for line in out.splitlines() if line.startswith("{")]
+    for line in out.splitlines():      # anything else rank 0 wrote to stdout (library chatter) goes to stderr
+        if not line.startswith("{"):
+            print(line, file=sys.stderr)
+    sys.stdout.write("".join(line + "\n" for line in json_lines))
     sys.stdout.flush()
     if rc == 0 and not any(line.startswith("{") for line in out.splitlines()):
         print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
@@ -305,7 +309,16 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on the C stdout: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     wl = WORKLOADS[args.workload]
     H, W = (args.size, args.size) if args.size else wl["shape"]
