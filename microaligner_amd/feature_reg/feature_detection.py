@@ -19,14 +19,34 @@ RATIO = 0.5                  # Lowe's ratio (feature_detection.py:143)
 
 class Features:
     """Keypoints + descriptors of one image (or tile).  `keypoints` is a list of KeyPoint (pt, size, angle,
-    response, octave, class_id -- the cv2.KeyPoint fields the reference serialises) or None."""
+    response, octave, class_id -- the cv2.KeyPoint fields the reference serialises) or None.  The device path keeps
+    the points as arrays (`pts` (n, 2) float64 (x, y), `responses` (n,)) and builds the KeyPoint list only when somebody
+    asks for it: a level of a 4096^2 image has ~45 000 of them per image and iteration."""
 
     def __init__(self):
-        self.keypoints: Optional[List[KeyPoint]] = None
+        self._keypoints: Optional[List[KeyPoint]] = None
+        self.pts: Optional[np.ndarray] = None
+        self.responses: Optional[np.ndarray] = None
         self.descriptors: Optional[np.ndarray] = None
 
+    @property
+    def keypoints(self) -> Optional[List[KeyPoint]]:
+        if self._keypoints is None and self.pts is not None:
+            self._keypoints = [KeyPoint((float(x), float(y)), 7.0, -1.0, float(r), 0, -1)
+                               for (x, y), r in zip(self.pts, self.responses)]
+        return self._keypoints
+
+    @keypoints.setter
+    def keypoints(self, kps):
+        self._keypoints = kps
+        if kps is not None:
+            self.pts = np.array([k.pt for k in kps], np.float64).reshape(-1, 2)
+            self.responses = np.array([k.response for k in kps], np.float64)
+        else:
+            self.pts = self.responses = None
+
     def is_valid(self) -> bool:
-        return self.keypoints is not None and self.descriptors is not None
+        return self.pts is not None and self.descriptors is not None
 
 
 def view_tile_without_overlap(img, overlap):
@@ -60,8 +80,8 @@ def match_features(img1_features: Features, img2_features: Features, verbose: bo
     identity = np.eye(2, 3)
     if not img1_features.is_valid() or not img2_features.is_valid():
         return identity
-    kp1, des1 = img1_features.keypoints, img1_features.descriptors
-    kp2, des2 = img2_features.keypoints, img2_features.descriptors
+    pts1, des1 = img1_features.pts, img1_features.descriptors
+    pts2, des2 = img2_features.pts, img2_features.descriptors
     if len(des1) < 2:
         return identity
     idx, dist = (knn or knn2)(des2, des1)
@@ -70,8 +90,8 @@ def match_features(img1_features: Features, img2_features: Features, verbose: bo
         print("    Good matches", len(good), "/", len(des2))
     if len(good) < 3:
         return identity
-    src_pts = np.array([kp1[i].pt for i in idx[good, 0]], np.float32)
-    dst_pts = np.array([kp2[i].pt for i in good], np.float32)
+    src_pts = pts1[idx[good, 0]].astype(np.float32)
+    dst_pts = pts2[good].astype(np.float32)
     mat, _ = estimate_affine_partial_2d(dst_pts, src_pts, confidence=0.99)
     return identity if mat is None else mat
 
@@ -128,8 +148,9 @@ def find_features_device(tile_list: Sequence[np.ndarray], ctx) -> List[Features]
     for t, (xs, ys, resp) in picked.items():
         n = len(xs)
         if n >= 3:
-            feats[t].keypoints = [KeyPoint((float(x), float(y)), 7.0, -1.0, float(r), 0, -1) for x, y, r in zip(xs, ys, resp)]
-            feats[t].descriptors = des[pos:pos + n].copy()
+            feats[t].pts = np.stack([xs, ys], 1).astype(np.float64)
+            feats[t].responses = resp.astype(np.float64)
+            feats[t].descriptors = des[pos:pos + n]
         pos += n
     return feats
 

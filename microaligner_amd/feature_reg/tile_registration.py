@@ -7,7 +7,6 @@ import numpy as np
 from ..shared_modules.tiling import TileGrid
 from .feature_detection import (TILE_OVERLAP, Features, find_features_device, find_features_parallelized,
                                 match_features)
-from .sparse_cpu import KeyPoint
 
 
 def split_image_into_tiles(img: np.ndarray, tile_size: int):
@@ -29,17 +28,18 @@ def combine_features(feature_list: List[Features], x_ntiles: int, y_ntiles: int,
                      tile_size_y: int) -> Features:
     """Keypoints of every tile moved to image coordinates (tile origin + interior coordinate), descriptors
     concatenated in the same order (tile_registration.py:37-74)."""
-    keypoints, descriptors = [], []
+    pts, responses, descriptors = [], [], []
     for tile_id, f in enumerate(feature_list):
         if not f.is_valid():
             continue
-        ox, oy = tile_id % x_ntiles * tile_size_x, tile_id // x_ntiles * tile_size_y
+        origin = np.array([tile_id % x_ntiles * tile_size_x, tile_id // x_ntiles * tile_size_y], np.float64)
+        pts.append(f.pts + origin)
+        responses.append(f.responses)
         descriptors.append(f.descriptors)
-        keypoints.extend(KeyPoint((ox + kp.pt[0], oy + kp.pt[1]), kp.size, kp.angle, kp.response, kp.octave,
-                                  kp.class_id) for kp in f.keypoints)
     combined = Features()
-    if keypoints and descriptors:
-        combined.keypoints = keypoints
+    if pts:
+        combined.pts = np.concatenate(pts, axis=0)
+        combined.responses = np.concatenate(responses)
         combined.descriptors = np.concatenate(descriptors, axis=0)
     return combined
 
