@@ -151,3 +151,22 @@ def test_ragged_shapes_at_the_default_tile_size_equal_the_oracle(shape, dtype, p
     sizes."""
     ref, mov = synthetic.make_pair(*shape, seed=31, dtype=dtype)
     _compare(ref, mov, params, f"ragged {shape} {np.dtype(dtype).name}")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_mid_size_configurations_equal_the_oracle(seed):
+    """Seeded random shapes between 1100 and 3300 px with production-like tilings (tile 500-1000, overlap 60-100, i.e.
+    windows of 59-99 taps: the streaming and the tiled vertical pass, windows with and without tail taps), random dtype,
+    DOG on / off, 1-3 iterations, with / without the full-resolution level."""
+    rng = np.random.default_rng(7000 + seed)
+    H, W = int(rng.integers(1100, 3300)), int(rng.integers(1100, 3300))
+    dtype = [np.uint8, np.uint16, np.float32][int(rng.integers(0, 3))]
+    tile = int(rng.choice([500, 640, 800, 1000]))
+    overlap = int(rng.choice([60, 71, 86, 100]))
+    params = dict(num_pyr_lvl=int(rng.integers(1, 4)), num_iterations=int(rng.integers(1, 4)), tile_size=tile,
+                  overlap=overlap, use_full_res_img=bool(rng.integers(0, 2)), use_dog=bool(rng.integers(0, 2)))
+    if rng.integers(0, 5) == 0:
+        ref, mov = synthetic.make_unrelated_pair(H, W, seed, dtype)
+    else:
+        ref, mov = synthetic.make_pair(H, W, seed, dtype)
+    _compare(ref, mov, params, f"random {H}x{W} {np.dtype(dtype).name} {params}")
