@@ -170,3 +170,42 @@ def test_random_mid_size_configurations_equal_the_oracle(seed):
     else:
         ref, mov = synthetic.make_pair(H, W, seed, dtype)
     _compare(ref, mov, params, f"random {H}x{W} {np.dtype(dtype).name} {params}")
+
+
+@pytest.mark.skipif(not BIG_HOST, reason=f"the 8192^2 oracle runs need >= 64 host cores (this host: {CORES})")
+def test_cfg4_cycle_chain_at_8192_equals_the_oracle_pipeline():
+    """BASELINE cfg4 as the pipeline runs it (__main__.py:398-433), at the stated cycle size: TCZYX cycles of 8192^2
+    uint16 pages, the reference channel's z pages max-projected and normalised to uint8 on the device, every cycle
+    registered against the PREVIOUS cycle's warped reference image (the chain), every page of the cycle warped with
+    that one flow by the page-warp driver.  Three cycles here (the chain is serial; eight only repeat the step)."""
+    from microaligner_amd import parallel
+    H = W = 8192
+    base, _ = synthetic.make_pair(H + 64, W + 64, 41)
+    rng = np.random.default_rng(42)
+    cycles = []
+    for cyc in range(3):
+        dy, dx = 4 * cyc, 3 * cyc                      # every cycle drifts a little further
+        crop = base[32 + dy:32 + dy + H, 32 + dx:32 + dx + W]
+        stack = np.empty((1, 2, H, W), np.uint16)      # (C, Z, H, W)
+        for z, gain in enumerate((1.0, 0.7)):
+            stack[0, z] = np.clip(crop * (180.0 * gain) + rng.normal(0, 25, crop.shape).astype(np.float32), 0, 65535).astype(np.uint16)
+        cycles.append(stack)
+    params = dict(num_pyr_lvl=3, use_full_res_img=True, use_dog=False)
+    t0 = time.perf_counter()
+    aligned, flows = parallel.register_cycle_chain(cycles, ref_channel_ids=[0, 0, 0], params=params)
+    t1 = time.perf_counter()
+    O.set_threads(CORES)
+
+    def conditioned(stack):
+        return O.normalize_minmax_u8(np.maximum.reduce(list(stack[0])).astype(np.float32))
+
+    ref = conditioned(cycles[0])
+    assert np.array_equal(aligned[0], cycles[0]) and flows[0] is None
+    for cyc in (1, 2):
+        mov = conditioned(cycles[cyc])
+        flow, _ = RO.register(ref, mov, nthreads=CORES, **params)
+        assert np.array_equal(flows[cyc], flow), cyc
+        ref = RO.warp(mov, flow, 1000, 100)
+        for z in range(2):
+            assert np.array_equal(aligned[cyc][0, z], RO.warp(cycles[cyc][0, z], flow, 1000, 100)), (cyc, z)
+    print(f"\n[cfg4 chain, 3 cycles x 2 pages of 8192^2 u16] HIP {t1 - t0:.2f} s, oracle {time.perf_counter() - t1:.1f} s")
