@@ -302,7 +302,7 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
 // window over an LDS-staged column strip:  s = c*k0;  s = (dn_i + up_i)*k_i + s  for i = 1..m.
 // ---------------------------------------------------------------------------------------------
 // occupancy targets (waves per SIMD) passed to __launch_bounds__; tuned on MI355X (profiles/r01_notes.md)
-constexpr int BV_WAVES = 6, BH_WAVES = 6;
+constexpr int BV_WAVES = 6, BH_WAVES = 4;
 template <int R, int NW, bool FUSED>
 __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v(FbGeom g, int m, const float* __restrict__ taps,
                                                      float* __restrict__ ws, int nplanes, int reach)
@@ -805,7 +805,8 @@ constexpr int BV_R = 14, BV_NW = 4;   // fb_blur_v: 64 columns x (NW*R) = 56 row
                                       // 49 tap pairs are 7 full groups of R/2 and the strip (158 rows) lets 4 blocks share a CU
 constexpr int BVS_NW = 8;             // fb_blur_v_stream: chunks of 8 x 14 = 112 rows, ring of 214 + 22 rows = 60 KB, 2 blocks / CU
                                       // (measured per launch: 4 waves 1.55 ms, 6 waves 1.70, 8 waves 1.53, 16 waves 1.84; tiled form 1.67)
-constexpr int BH_R = 8, BH_NW = 8;    // fb_blur_h_solve: 64 rows x 64 columns per block
+constexpr int BH_R = 14, BH_NW = 8;   // fb_blur_h_solve: 64 rows x 112 columns per block (56 KB tile, 2 blocks / CU, 4 waves / SIMD at
+                                      // ~124 VGPRs; measured per launch: R 8 x 8 waves 2.142 ms, R 14 x 4 waves 2.227, R 14 x 8 waves 2.104)
 constexpr size_t LDS_MAX = 160 * 1024;
 
 template <typename T, bool FUSED>
@@ -865,8 +866,8 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
             {
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px_h[it]);
                 const long long items = (long long)((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R)) * ((Ph + 63) / 64) * ma_xcd_slots(nwin);
-                if (colsh <= 192)
-                    hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 3>), dim3(ma_xcd_grid(items)),
+                if (colsh <= 256)
+                    hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 4>), dim3(ma_xcd_grid(items)),
                                        dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin, reach);
                 else
                     hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 5>), dim3(ma_xcd_grid(items)),
