@@ -866,12 +866,13 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
             {
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px_h[it]);
                 const long long items = (long long)((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R)) * ((Ph + 63) / 64) * ma_xcd_slots(nwin);
-                if (colsh <= 256)
-                    hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 4>), dim3(ma_xcd_grid(items)),
-                                       dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin, reach);
-                else
-                    hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, 5>), dim3(ma_xcd_grid(items)),
-                                       dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin, reach);
+                // Q = 64-column chunks of the staged row tile (112 + 2m + 4 columns)
+#define MA_BLUR_H(QQ) hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, QQ>), dim3(ma_xcd_grid(items)), dim3(64 * BH_NW), \
+                                         lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin, reach)
+                if (colsh <= 192) MA_BLUR_H(3);
+                else if (colsh <= 256) MA_BLUR_H(4);
+                else MA_BLUR_H(5);
+#undef MA_BLUR_H
             }
         } else {
             {
