@@ -72,6 +72,21 @@ def test_farneback_tiled_bit_exact(ctx, shape, tile, ov, dtype):
     assert np.array_equal(got, exp), f"max abs diff {np.abs(got - exp).max()}"
 
 
+@pytest.mark.parametrize("win", [3, 15, 29, 57, 77, 79, 99, 141, 143, 199, 253])
+def test_farneback_every_window_size_class_bit_exact(ctx, win):
+    """The window-blur kernels pick their form from the window: the streaming vertical pass (tap pairs a multiple of
+    7) or the tiled one with tail taps; 3, 4 or 5 staged column chunks in the horizontal pass; beyond 253 taps the
+    plain fallback kernels.  One window size from every class, untiled and tiled, against the oracle."""
+    ref, mov = pair(330, 410, 50 + win)
+    exp = O.calc_optical_flow_farneback(mov, ref, win, 2)
+    got = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), win, 2).numpy()
+    assert np.array_equal(got, exp)
+    if win <= 99:
+        exp = RO.tile_flow(ref, mov, 200, 50, win, 3)
+        got = ctx.farneback(ctx.asdevice(mov), ctx.asdevice(ref), win, 3, tile=200, overlap=50).numpy()
+        assert np.array_equal(got, exp)
+
+
 def test_farneback_full_size_tile_bit_exact(ctx):
     """One reference-sized window: 1200 x 1200, winsize 99, 3 iterations."""
     ref, mov = pair(1200, 1200, 42)
