@@ -260,8 +260,11 @@ __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict
 // One block owns a 64-column strip and streams down LY rows of it.  The row-filtered rows of both sigmas live in
 // LDS (CB, [sigma][rows][64]); per super-step of S = NW*R output rows the block
 //   1. stages 2 x 32 normalised input rows (+-20 halo columns, reflect-101) and row-filters them into CB rows
-//      [CARRY, CARRY + S)  -- same register-pair scheme as dog_rows: 4 outputs per thread from 16-byte LDS reads of
-//      the row (copy A) and the row shifted by one element (copy B), taps broadcast from SGPRs;
+//      [CARRY, CARRY + S)  -- 4 outputs per thread as two register pairs per sigma, inputs from 16-byte LDS reads of
+//      the staged row (even-offset pairs) and of the same row one element on (odd-offset pairs), taps broadcast
+//      from SGPRs.  The staged rows have a pitch of 128 floats: on gfx950 a 16-byte-per-lane LDS read is free of
+//      bank conflicts only when the 256 bytes a group of 16 lanes reads start on a 128-byte boundary (SQ counters:
+//      22 % of the LDS-active cycles were conflicts at pitches of 104 .. 136 floats, 0.5 % at 128);
 //   2. runs the symmetric column filter for both sigmas from CB (d_sym_fir_slide_pk, as dog_cols_diff), writes
 //      hs - ls and folds the min / max;
 //   3. moves the last CARRY = 2r + 2 rows of CB to the top: they are the halo of the next super-step.
@@ -274,8 +277,8 @@ constexpr int DF_KS = 41, DF_RAD = 20, DF_G = 1;          // guard row: d_sym_fi
 constexpr int DF_CARRY = 2 * DF_RAD + 2 * DF_G;           // 42
 constexpr int DF_CBROWS = DF_S + DF_CARRY;                // 106
 constexpr int DF_CH = 32;                                 // rows per row-filter chunk (512 threads x 4 columns)
-constexpr int DF_SPAN = 64 + 2 * DF_RAD;                  // 104 staged columns per row
-constexpr size_t df_lds(int sp) { return (size_t)(2 * DF_CH * sp + 2 * DF_CBROWS * 64) * sizeof(float); }  // <= 81 920 B: 2 blocks / CU
+constexpr int DF_PITCH = 128;                             // floats per staged row: rows start on 512-byte boundaries
+constexpr size_t df_lds(int sp) { return (size_t)(DF_CH * sp + 2 * DF_CBROWS * 64) * sizeof(float); }  // 70 656 B: 2 blocks / CU
 
 template <typename T, int DF_SP>
 __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__ src, int h, int w, int LY, int nstrips,
@@ -286,8 +289,7 @@ __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__
 {
     extern __shared__ float lds[];
     float* A = lds;                         // [DF_CH][DF_SP]   A[row][c] = v[c]
-    float* B = A + DF_CH * DF_SP;           // [DF_CH][DF_SP]   B[row][c] = v[c + 1]
-    float* CB = B + DF_CH * DF_SP;          // [2][DF_CBROWS][64]
+    float* CB = A + DF_CH * DF_SP;          // [2][DF_CBROWS][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // strips fastest: neighbouring strips (which share 40 of their 104 input columns) are consecutive items of one XCD
@@ -315,8 +317,7 @@ __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__
             const int row = wv * 4 + k;
             const float fa = __fadd_rn(__fmul_rn(va[k], a), b), fb = __fadd_rn(__fmul_rn(vb[k], a), b);
             A[row * DF_SP + lane] = fa;
-            if (lane > 0) B[row * DF_SP + lane - 1] = fa;
-            if (lane < 2 * DF_RAD) { A[row * DF_SP + 64 + lane] = fb; B[row * DF_SP + 63 + lane] = fb; }
+            if (lane < 2 * DF_RAD) A[row * DF_SP + 64 + lane] = fb;
         }
     };
     // row filter of the staged chunk into CB rows [cb0, cb0 + nrows): thread = 4 consecutive columns of one row
@@ -327,10 +328,12 @@ __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__
         constexpr int KMAX = (DF_KS + 3 + 3) / 4 * 4;   // 44 inputs per thread
         ma_f2 E[KMAX / 2], O[KMAX / 2];
         const float4* a4 = reinterpret_cast<const float4*>(A + rrow * DF_SP + 4 * rq);
-        const float4* b4 = reinterpret_cast<const float4*>(B + rrow * DF_SP + 4 * rq);
+        const float* b1 = A + rrow * DF_SP + 4 * rq + 1;   // the same row one element on: the odd-offset pairs
 #pragma unroll
         for (int q = 0; q < KMAX / 4; q++) {
-            const float4 t = a4[q], u = b4[q];
+            const float4 t = a4[q];
+            float4 u;                                       // (v[4q+1] .. v[4q+4]): the compiler takes them from the
+            __builtin_memcpy(&u, b1 + 4 * q, 16);           // aligned reads of this and the next group
             E[2 * q] = (ma_f2){t.x, t.y}; E[2 * q + 1] = (ma_f2){t.z, t.w};
             O[2 * q] = (ma_f2){u.x, u.y}; O[2 * q + 1] = (ma_f2){u.z, u.w};
         }
@@ -579,10 +582,9 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
     if (fused) {
         const dim3 grid(ma_xcd_grid((long long)nblk)), block(64 * DF_NW);
 #define MA_DOG_FUSED(T, SP) hipLaunchKernelGGL((dog_fused<T, SP>), grid, block, df_lds(SP), ctx->stream, (const T*)src, h, w, LY, nstrips, nseg, sc, dlo, dloc, dhic, diff, part)
-        // row pitch of the staged input = its 104 columns (a padded pitch of 108 measured the same: 0.601-0.605 ms)
-        if (dtype == MA_U8) MA_DOG_FUSED(uint8_t, DF_SPAN);
-        else if (dtype == MA_U16) MA_DOG_FUSED(uint16_t, DF_SPAN);
-        else MA_DOG_FUSED(float, DF_SPAN);
+        if (dtype == MA_U8) MA_DOG_FUSED(uint8_t, DF_PITCH);
+        else if (dtype == MA_U16) MA_DOG_FUSED(uint16_t, DF_PITCH);
+        else MA_DOG_FUSED(float, DF_PITCH);
 #undef MA_DOG_FUSED
     } else {
         {
