@@ -260,9 +260,9 @@ __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict
 // One block owns a 64-column strip and streams down LY rows of it.  The row-filtered rows of both sigmas live in
 // LDS (CB, [sigma][rows][64]); per super-step of S = NW*R output rows the block
 //   1. stages 2 x 32 normalised input rows (+-20 halo columns, reflect-101) and row-filters them into CB rows
-//      [CARRY, CARRY + S)  -- 4 outputs per thread as two register pairs per sigma, inputs from 16-byte LDS reads of
-//      the staged row (even-offset pairs) and of the same row one element on (odd-offset pairs), taps broadcast
-//      from SGPRs.  The staged rows have a pitch of 128 floats: on gfx950 a 16-byte-per-lane LDS read is free of
+//      [CARRY, CARRY + S)  -- 4 outputs per thread, one (sigma_lo, sigma_hi) accumulator pair per output; the 44
+//      inputs come from 16-byte LDS reads of the staged row, tap pairs (k_lo, k_hi) from SGPRs, and a packed op takes
+//      its input by half-select of the register pair that holds it.  The staged rows have a pitch of 128 floats: on gfx950 a 16-byte-per-lane LDS read is free of
 //      bank conflicts only when the 256 bytes a group of 16 lanes reads start on a 128-byte boundary (SQ counters:
 //      22 % of the LDS-active cycles were conflicts at pitches of 104 .. 136 floats, 0.5 % at 128);
 //   2. runs the symmetric column filter for both sigmas from CB (d_sym_fir_slide_pk, as dog_cols_diff), writes
@@ -326,32 +326,31 @@ __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__
     auto row_filter = [&](int cb0, int nrows) {
         if (rrow >= nrows) return;
         constexpr int KMAX = (DF_KS + 3 + 3) / 4 * 4;   // 44 inputs per thread
-        ma_f2 E[KMAX / 2], O[KMAX / 2];
+        ma_f2 E[KMAX / 2];                               // E[q] = (v[2q], v[2q+1])
         const float4* a4 = reinterpret_cast<const float4*>(A + rrow * DF_SP + 4 * rq);
-        const float* b1 = A + rrow * DF_SP + 4 * rq + 1;   // the same row one element on: the odd-offset pairs
 #pragma unroll
         for (int q = 0; q < KMAX / 4; q++) {
             const float4 t = a4[q];
-            float4 u;                                       // (v[4q+1] .. v[4q+4]): the compiler takes them from the
-            __builtin_memcpy(&u, b1 + 4 * q, 16);           // aligned reads of this and the next group
             E[2 * q] = (ma_f2){t.x, t.y}; E[2 * q + 1] = (ma_f2){t.z, t.w};
-            O[2 * q] = (ma_f2){u.x, u.y}; O[2 * q + 1] = (ma_f2){u.z, u.w};
         }
-        ma_f2 lo01, lo23, hi01, hi23;
+        // One accumulator pair per output: (sigma_lo, sigma_hi).  Tap j multiplies the tap pair (k_lo[j], k_hi[j]) from
+        // SGPRs by input v[o + j] broadcast to both halves -- a half-select of the register pair that holds it, no
+        // move -- so odd and even offsets cost the same and every input is read from LDS once.
+        auto V = [&](int i) { const float x = (i & 1) ? E[i >> 1].y : E[i >> 1].x; return (ma_f2){x, x}; };
+        ma_f2 acc[4];
         {
             const ma_f2 k = kk[0];
-            const ma_f2 kl = {k.x, k.x}, kh = {k.y, k.y};
-            lo01 = E[0] * kl; lo23 = E[1] * kl; hi01 = E[0] * kh; hi23 = E[1] * kh;
+#pragma unroll
+            for (int o = 0; o < 4; o++) acc[o] = V(o) * k;
         }
 #pragma unroll
         for (int j = 1; j < DF_KS; j++) {
             const ma_f2 k = kk[j];
-            const ma_f2 kl = {k.x, k.x}, kh = {k.y, k.y};
-            const ma_f2 d01 = (j & 1) ? O[(j - 1) / 2] : E[j / 2];
-            const ma_f2 d23 = (j & 1) ? O[(j - 1) / 2 + 1] : E[j / 2 + 1];
-            lo01 = lo01 + d01 * kl; lo23 = lo23 + d23 * kl;
-            hi01 = hi01 + d01 * kh; hi23 = hi23 + d23 * kh;
+#pragma unroll
+            for (int o = 0; o < 4; o++) acc[o] = acc[o] + V(o + j) * k;
         }
+        const ma_f2 lo01 = {acc[0].x, acc[1].x}, lo23 = {acc[2].x, acc[3].x};
+        const ma_f2 hi01 = {acc[0].y, acc[1].y}, hi23 = {acc[2].y, acc[3].y};
         float* clo = CB + (cb0 + rrow) * 64 + 4 * rq;
         *reinterpret_cast<float4*>(clo) = make_float4(lo01.x, lo01.y, lo23.x, lo23.y);
         *reinterpret_cast<float4*>(clo + DF_CBROWS * 64) = make_float4(hi01.x, hi01.y, hi23.x, hi23.y);
