@@ -144,7 +144,7 @@ int ma_warp_tiled(ma_ctx* ctx, const void* img, int dtype, int H, int W, const f
  * with max; order-preserving unsigned keys, NaN = largest), from which
  * ma_merge_flows_tiled_cells derives the per-window flow.max() tests of merge_two_flows
  * (optflow_registrator.py:38-42) without reading the flows again.  Requires tile > 2*overlap > 0. */
-#define MA_FLOW_CELL_REPLICAS 32
+#define MA_FLOW_CELL_REPLICAS 8
 int ma_warp_tiled_flowcells(ma_ctx* ctx, const void* img, int dtype, int H, int W, const float* flow, int tile,
                             int overlap, void* out, float* minmax_dev, unsigned* flow_cellkeys_dev);
 

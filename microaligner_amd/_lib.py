@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmicroaligner_hip.so")
 MA_U8, MA_U16, MA_F32 = 0, 1, 2
 MA_OK, MA_EINVAL, MA_ENOMEM, MA_EHIP, MA_ENODEV = 0, -1, -2, -3, -4
 MA_FB_MULADD_FUSED = 1
-MA_FLOW_CELL_REPLICAS = 32
+MA_FLOW_CELL_REPLICAS = 8
 
 KERNEL_IDS = {"polyexp_m0": 0, "blur_v": 1, "blur_h_solve": 2, "warp": 3, "merge": 4, "pyr_down": 5,
               "pyr_up": 6, "dog": 7, "nmi": 8, "other": 9}

@@ -185,7 +185,7 @@ __device__ __forceinline__ int d_segment(int v, int T, int ov)
 // WARP_ROWS rows per thread: the flow loads of all rows are issued before the first gather, the gathers of all
 // rows before the first store -- 8 rows in flight per thread run 1.4x faster than one (measured, profiles/r01_notes.md)
 constexpr int WARP_ROWS = 8;
-constexpr int CELL_REPLICAS = 32;   // copies of the flow cell-maxima array (ma_warp_tiled_flowcells)
+constexpr int CELL_REPLICAS = 8;    // copies of the flow cell-maxima array (ma_warp_tiled_flowcells); 8 / 32 / 128 copies: warp 0.39 ms each, merge 0.26 / 0.29 / 0.36
 // MM: also reduce (min, max) of the block's output pixels into part[2 * block] (input conditioning of a following
 // dog(): the consumer then skips its own pass over the image)
 // cellkeys (may be NULL; needs T > 2*ov > 0): also fold the maximum of both FLOW components over the cells the window
