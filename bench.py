@@ -100,6 +100,11 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
            "avg_launch_ms": round(rec["ms"] / rec["launches"], 4), "launches": rec["launches"],
            "algorithmic_bytes_per_launch": round(bpp * rec["px"] / rec["launches"]),
            "algorithmic_bytes_per_px": round(bpp, 2), "px_per_launch": round(rec["px"] / rec["launches"])}
+    if traffic is not None and traffic < 0.8 * out["algorithmic_bytes_per_launch"]:
+        # fewer HBM bytes than algorithmic bytes: the producer's output is still in L2 / the 256 MB infinity cache and
+        # write-backs complete after the kernel; `achieved` (algorithmic bytes per second) can then exceed the HBM peak
+        out["note"] = ("PMC traffic below the algorithmic bytes: part of this kernel's data is served by L2 / infinity "
+                       "cache; `achieved` is not pure HBM bandwidth")
     if name in ("blur_v", "blur_h_solve") and winsize_taps:
         # informational: these two kernels are bound by packed-FP32 issue, not by HBM.  FIR work = 5 planes x
         # (3 lane-ops per tap pair + 1) per pixel; peak = the v_pk_mul_f32 rate measured on this GPU
