@@ -152,15 +152,21 @@ int minmax_host(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn, d
     return MA_OK;
 }
 
+// v*a + b of cv2.normalize's convertTo, in either rounding model (MA_DOG_FUSED_SCALE)
+__device__ __forceinline__ float d_scale(int fused, float v, float a, float b)
+{
+    return fused ? __fmaf_rn(v, a, b) : __fadd_rn(__fmul_rn(v, a), b);
+}
+
 // ---- DOG row pass, any kernel size (the fallback chain for sizes other than the reference's 41) ----------
 // Block: 256 output columns x DR rows.  The normalised input row segment (+- r halo, reflect-101) is staged in
 // LDS; a thread produces 4 consecutive columns of one row, accumulating both kernels left to right over the
 // ksize taps (acc = k0*v0, then acc = acc + k_j*v_j for ascending j).
 constexpr int DR = 4;
-template <typename T>
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h, int w, int ksize,
                                                 const DogScalars* __restrict__ sc, const float* __restrict__ klh,
-                                                float* __restrict__ tlo, float* __restrict__ thi)
+                                                float* __restrict__ tlo, float* __restrict__ thi, int fused_scale)
 {
     extern __shared__ float lds[];  // [DR][256 + 2r]
     const int r = ksize / 2, span = 256 + 2 * r;
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h
     for (int row = 0; row < DR; row++) {
         const T* s = src + (size_t)min(y0 + row, h - 1) * w;
         for (int c = threadIdx.x; c < span; c += 256)
-            lds[row * span + c] = __fadd_rn(__fmul_rn((float)s[d_reflect101(x0 - r + c, w)], a), b);
+            lds[row * span + c] = d_scale(fused_scale, (float)s[d_reflect101(x0 - r + c, w)], a, b);
     }
     __syncthreads();
     const int row = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -182,8 +188,12 @@ __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h
         ma_f2 s2 = kk[0] * (ma_f2){v[0], v[0]};
         for (int j = 1; j < ksize; j++) {
             const float vj = v[j];
-            const ma_f2 p = kk[j] * (ma_f2){vj, vj};
-            s2 = s2 + p;
+            if (FUSED) {
+                s2 = __builtin_elementwise_fma(kk[j], (ma_f2){vj, vj}, s2);
+            } else {
+                const ma_f2 p = kk[j] * (ma_f2){vj, vj};
+                s2 = s2 + p;
+            }
         }
         if (x + o < w) { tlo[(size_t)y * w + x + o] = s2.x; thi[(size_t)y * w + x + o] = s2.y; }
     }
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void dog_rows(const T* __restrict__ src, int h
 // ---- DOG column pass + difference + per-block min/max ---------------------------------------------
 // Block: 64 columns x (NW*R) rows; per array the column strip (+- r halo rows, reflect-101) is staged in LDS and
 // the symmetric filter slides a register window down the column (d_sym_fir_slide).
-template <int R, int NW>
+template <int R, int NW, bool FUSED>
 __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict__ tlo, const float* __restrict__ thi,
                                                          int h, int w, int ksize, const float* __restrict__ klo_c,
                                                          const float* __restrict__ khi_c, float* __restrict__ diff,
@@ -226,8 +236,8 @@ __global__ __launch_bounds__(64 * NW) void dog_cols_diff(const float* __restrict
             }
         }
         __syncthreads();
-        if (arr == 0) d_sym_fir_slide_pk<R, false, true>(lds + lane, G + r + wv * R, r, klo_c, sl);
-        else d_sym_fir_slide_pk<R, false, true>(lds + lane, G + r + wv * R, r, khi_c, sh);
+        if (arr == 0) d_sym_fir_slide_pk<R, FUSED, true>(lds + lane, G + r + wv * R, r, klo_c, sl);
+        else d_sym_fir_slide_pk<R, FUSED, true>(lds + lane, G + r + wv * R, r, khi_c, sh);
         __syncthreads();
     }
     float lo = INFINITY, hi = -INFINITY;
@@ -280,12 +290,12 @@ constexpr int DF_CH = 32;                                 // rows per row-filter
 constexpr int DF_PITCH = 128;                             // floats per staged row: rows start on 512-byte boundaries
 constexpr size_t df_lds(int sp) { return (size_t)(DF_CH * sp + 2 * DF_CBROWS * 64) * sizeof(float); }  // 70 656 B: 2 blocks / CU
 
-template <typename T, int DF_SP>
+template <typename T, int DF_SP, bool FUSED>
 __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__ src, int h, int w, int LY, int nstrips,
                                                           int nseg, const DogScalars* __restrict__ sc,
                                                           const float* __restrict__ klh, const float* __restrict__ klo_c,
                                                           const float* __restrict__ khi_c, float* __restrict__ diff,
-                                                          float* __restrict__ part)
+                                                          float* __restrict__ part, int fused_scale)
 {
     extern __shared__ float lds[];
     float* A = lds;                         // [DF_CH][DF_SP]   A[row][c] = v[c]
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int row = wv * 4 + k;
-            const float fa = __fadd_rn(__fmul_rn(va[k], a), b), fb = __fadd_rn(__fmul_rn(vb[k], a), b);
+            const float fa = d_scale(fused_scale, va[k], a, b), fb = d_scale(fused_scale, vb[k], a, b);
             A[row * DF_SP + lane] = fa;
             if (lane < 2 * DF_RAD) A[row * DF_SP + 64 + lane] = fb;
         }
@@ -347,7 +357,10 @@ __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__
         for (int j = 1; j < DF_KS; j++) {
             const ma_f2 k = kk[j];
 #pragma unroll
-            for (int o = 0; o < 4; o++) acc[o] = acc[o] + V(o + j) * k;
+            for (int o = 0; o < 4; o++) {
+                if (FUSED) acc[o] = __builtin_elementwise_fma(V(o + j), k, acc[o]);
+                else acc[o] = acc[o] + V(o + j) * k;
+            }
         }
         const ma_f2 lo01 = {acc[0].x, acc[1].x}, lo23 = {acc[2].x, acc[3].x};
         const ma_f2 hi01 = {acc[0].y, acc[1].y}, hi23 = {acc[2].y, acc[3].y};
@@ -384,8 +397,8 @@ __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__
         __syncthreads();
         {
             float sl[DF_R], sh[DF_R];
-            d_sym_fir_slide_pk<DF_R, false, true>(CB + lane, DF_G + DF_RAD + wv * DF_R, DF_RAD, klo_c, sl);
-            d_sym_fir_slide_pk<DF_R, false, true>(CB + DF_CBROWS * 64 + lane, DF_G + DF_RAD + wv * DF_R, DF_RAD, khi_c, sh);
+            d_sym_fir_slide_pk<DF_R, FUSED, true>(CB + lane, DF_G + DF_RAD + wv * DF_R, DF_RAD, klo_c, sl);
+            d_sym_fir_slide_pk<DF_R, FUSED, true>(CB + DF_CBROWS * 64 + lane, DF_G + DF_RAD + wv * DF_R, DF_RAD, khi_c, sh);
             const int x = x0 + lane;
 #pragma unroll
             for (int q = 0; q < DF_R; q++) {
@@ -428,12 +441,13 @@ __global__ __launch_bounds__(64 * DF_NW, 2) void dog_fused(const T* __restrict__
 // use a quarter of a store instruction's width).
 template <typename T>
 __global__ __launch_bounds__(256) void scale_to_u8(const T* __restrict__ src, size_t n, float a, float b,
-                                                   const DogScalars* __restrict__ sc, uint8_t* __restrict__ dst)
+                                                   const DogScalars* __restrict__ sc, uint8_t* __restrict__ dst,
+                                                   int fused_scale)
 {
     bool zero = false;
     if (sc) { a = sc->a8; b = sc->b8; zero = sc->src_max_is_zero != 0; }
     auto cvt = [&](float x) -> unsigned {
-        float v = __fadd_rn(__fmul_rn(x, a), b);
+        float v = d_scale(fused_scale, x, a, b);
         return zero ? 0u : (unsigned)d_clamp(d_cvround(v), 0, 255);
     };
     const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
@@ -515,8 +529,11 @@ int ma_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn_host
 }
 
 static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst,
-                       int* src_max_is_zero_host, const float* src_minmax_dev)
+                       int* src_max_is_zero_host, const float* src_minmax_dev, int flags)
 {
+    MA_REQUIRE((flags & ~(MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE)) == 0, "unknown DOG flag");
+    const bool fblur = (flags & MA_DOG_FUSED_BLUR) != 0;
+    const int fscale = (flags & MA_DOG_FUSED_SCALE) != 0;
     MA_REQUIRE(ctx && src && dst, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
     MA_REQUIRE(h > 0 && w > 0, "bad image size");
@@ -580,7 +597,13 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
     hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc);
     if (fused) {
         const dim3 grid(ma_xcd_grid((long long)nblk)), block(64 * DF_NW);
-#define MA_DOG_FUSED(T, SP) hipLaunchKernelGGL((dog_fused<T, SP>), grid, block, df_lds(SP), ctx->stream, (const T*)src, h, w, LY, nstrips, nseg, sc, dlo, dloc, dhic, diff, part)
+#define MA_DOG_FUSED(T, SP)                                                                                                  \
+    do {                                                                                                                     \
+        if (fblur) hipLaunchKernelGGL((dog_fused<T, SP, true>), grid, block, df_lds(SP), ctx->stream, (const T*)src, h, w,   \
+                                      LY, nstrips, nseg, sc, dlo, dloc, dhic, diff, part, fscale);                          \
+        else hipLaunchKernelGGL((dog_fused<T, SP, false>), grid, block, df_lds(SP), ctx->stream, (const T*)src, h, w, LY,    \
+                                nstrips, nseg, sc, dlo, dloc, dhic, diff, part, fscale);                                    \
+    } while (0)
         if (dtype == MA_U8) MA_DOG_FUSED(uint8_t, DF_PITCH);
         else if (dtype == MA_U16) MA_DOG_FUSED(uint16_t, DF_PITCH);
         else MA_DOG_FUSED(float, DF_PITCH);
@@ -588,22 +611,27 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
     } else {
         {
             dim3 grid((w + 255) / 256, (h + DR - 1) / DR), block(256);
-#define MA_DOG_ROWS(T) hipLaunchKernelGGL((dog_rows<T>), grid, block, lds_rows, ctx->stream, (const T*)src, h, w, ksize, sc, dlo, tlo, thi)
+#define MA_DOG_ROWS(T)                                                                                                       \
+    do {                                                                                                                     \
+        if (fblur) hipLaunchKernelGGL((dog_rows<T, true>), grid, block, lds_rows, ctx->stream, (const T*)src, h, w, ksize,   \
+                                      sc, dlo, tlo, thi, fscale);                                                           \
+        else hipLaunchKernelGGL((dog_rows<T, false>), grid, block, lds_rows, ctx->stream, (const T*)src, h, w, ksize, sc,    \
+                                dlo, tlo, thi, fscale);                                                                     \
+    } while (0)
             if (dtype == MA_U8) MA_DOG_ROWS(uint8_t);
             else if (dtype == MA_U16) MA_DOG_ROWS(uint16_t);
             else MA_DOG_ROWS(float);
 #undef MA_DOG_ROWS
         }
-        if (DC_R == 10)
-            hipLaunchKernelGGL((dog_cols_diff<10, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
-                               ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
-        else
-            hipLaunchKernelGGL((dog_cols_diff<16, DC_NW>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), lds_cols,
-                               ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part);
+#define MA_DOG_COLS(RR, FF) hipLaunchKernelGGL((dog_cols_diff<RR, DC_NW, FF>), dim3(ma_xcd_grid((long long)nblk)), dim3(64 * DC_NW), \
+                                               lds_cols, ctx->stream, tlo, thi, h, w, ksize, dloc, dhic, diff, part)
+        if (DC_R == 10) { if (fblur) MA_DOG_COLS(10, true); else MA_DOG_COLS(10, false); }
+        else { if (fblur) MA_DOG_COLS(16, true); else MA_DOG_COLS(16, false); }
+#undef MA_DOG_COLS
     }
     hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, (int)nblk, sc->mm_diff);
     hipLaunchKernelGGL(dog_params_out, dim3(1), dim3(1), 0, ctx->stream, sc);
-    hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst);
+    hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst, fscale);
     MA_HIP(hipGetLastError());
     if (src_max_is_zero_host) {
         MA_TRY(ma_pinned_reserve(ctx, 64));
@@ -617,14 +645,20 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
 int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst,
               int* src_max_is_zero_host)
 {
-    return dog_u8_impl(ctx, src, dtype, h, w, low_sigma, high_sigma, dst, src_max_is_zero_host, nullptr);
+    return dog_u8_impl(ctx, src, dtype, h, w, low_sigma, high_sigma, dst, src_max_is_zero_host, nullptr, 0);
+}
+
+int ma_dog_u8_ex(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, int flags,
+                 const float* src_minmax_dev, uint8_t* dst, int* src_max_is_zero_host)
+{
+    return dog_u8_impl(ctx, src, dtype, h, w, low_sigma, high_sigma, dst, src_max_is_zero_host, src_minmax_dev, flags);
 }
 
 int ma_dog_u8_minmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma,
                      const float* src_minmax_dev, uint8_t* dst, int* src_max_is_zero_host)
 {
     MA_REQUIRE(src_minmax_dev, "NULL argument");
-    return dog_u8_impl(ctx, src, dtype, h, w, low_sigma, high_sigma, dst, src_max_is_zero_host, src_minmax_dev);
+    return dog_u8_impl(ctx, src, dtype, h, w, low_sigma, high_sigma, dst, src_max_is_zero_host, src_minmax_dev, 0);
 }
 
 int ma_max_project(ma_ctx* ctx, const void* planes, int dtype, int nz, size_t n, void* dst)
@@ -655,9 +689,9 @@ int ma_normalize_minmax_u8(ma_ctx* ctx, const void* src, int dtype, size_t n, ui
     MaProfScope ps(ctx, MA_K_OTHER, (double)n);
     dim3 grid(grid_for(n)), block(256);
     const DogScalars* none = nullptr;
-    if (dtype == MA_U8) hipLaunchKernelGGL((scale_to_u8<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)src, n, (float)scale, (float)shift, none, dst);
-    else if (dtype == MA_U16) hipLaunchKernelGGL((scale_to_u8<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)src, n, (float)scale, (float)shift, none, dst);
-    else hipLaunchKernelGGL((scale_to_u8<float>), grid, block, 0, ctx->stream, (const float*)src, n, (float)scale, (float)shift, none, dst);
+    if (dtype == MA_U8) hipLaunchKernelGGL((scale_to_u8<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)src, n, (float)scale, (float)shift, none, dst, 0);
+    else if (dtype == MA_U16) hipLaunchKernelGGL((scale_to_u8<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)src, n, (float)scale, (float)shift, none, dst, 0);
+    else hipLaunchKernelGGL((scale_to_u8<float>), grid, block, 0, ctx->stream, (const float*)src, n, (float)scale, (float)shift, none, dst, 0);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }

@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cfloat>
+#include <type_traits>
 
 namespace {
 
@@ -109,6 +110,9 @@ constexpr int NEED_XALIGN = 32;
 // ---------------------------------------------------------------------------------------------
 constexpr int K1_TX = 64, K1_TY = 16, K1_THREADS = 256;
 
+// NEAR_BORDER = false: the caller guarantees that the pixel is at least 5 px away from every window edge (a
+// block-uniform fact for all but the outermost blocks), and the attenuation test is not even compiled
+template <bool NEAR_BORDER = true>
 __device__ __forceinline__ void update_matrices_px(const float r0[5], float r2, float r3, float r4, float r5,
                                                    float r6, bool inside, float dx, float dy, int x, int y,
                                                    int w, int h, float out[5])
@@ -129,7 +133,7 @@ __device__ __forceinline__ void update_matrices_px(const float r0[5], float r2, 
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     const int BORDER = 5;
-    if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+    if (NEAR_BORDER && ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) || (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2))) {
         const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
         float scale = (x < BORDER ? border[x] : 1.f) * (x >= w - BORDER ? border[w - x - 1] : 1.f) *
                       (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
@@ -481,10 +485,12 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v_stream(FbGeom g, 
 // Block: 64 rows x (NW*R) columns.
 // ---------------------------------------------------------------------------------------------
 // Q = ceil((NW*R + 2m + 4) / 64): column chunks of the staged row tile
-template <int R, int NW, bool FUSED, int Q>
+// LAST: the final iteration only stores the centre crop of the flow; it is its own instantiation, so it carries
+// neither the code nor the registers of UpdateMatrices.
+template <int R, int NW, bool FUSED, int Q, bool LAST>
 __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, int m, const float* __restrict__ taps,
-                                                           float* __restrict__ ws, int last,
-                                                           float* __restrict__ flow_out, int nwin, int reach)
+                                                           float* __restrict__ ws, float* __restrict__ flow_out,
+                                                           int nwin, int reach)
 {
     extern __shared__ float lds[];
     constexpr int TXW = NW * R;           // output columns per block
@@ -505,7 +511,8 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
     window_extent(g, oy, ox, ey, ex);
     const FbRect need = needed_rect_h(g.t, oy, ox, reach);
     const int x0 = (need.x0 & ~(NEED_XALIGN - 1)) + bx * TXW, y0 = need.y0 + by * 64;
-    if (x0 >= min(ex, need.x1) || y0 >= min(ey, need.y1)) return;
+    const int xend = min(ex, need.x1), yend = min(ey, need.y1);   // needed AND possibly non-zero
+    if (x0 >= xend || y0 >= yend) return;
     constexpr int G = 2;  // guard columns on either side (d_sym_fir_slide contract)
     const int cols = TXW + 2 * m + 2 * G;
     const int lp = cols | 1;              // odd LDS pitch: lanes (rows) hit distinct banks
@@ -547,7 +554,7 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
     };
 
     float hs[5][R];
-    const bool wave_needed = x0 + w * R < min(ex, need.x1);  // else: this wave's columns feed nothing (it still stages)
+    const bool wave_needed = x0 + w * R < xend;  // else: this wave's columns feed nothing (it still stages)
     issue(0);
 #pragma unroll
     for (int ch = 0; ch < 5; ch++) {
@@ -568,37 +575,52 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
         __syncthreads();
     }
 
-    // transpose through LDS in two halves of 32 rows: tb[ch][32][TXW+1]
+    // 2x2 solve where the filter left its sums: in registers, lane = row, r = column.  Only the flow crosses LDS
+    // (one 8-byte store per pixel, all 64 lanes, one pass) on its way to the x-major mapping of the epilogue.
+    // Pitch TXW + 1 pairs: the 16 lanes of a store group start 2 banks apart.
     constexpr int TP = TXW + 1;
-    for (int half = 0; half < 2; half++) {
-        if ((lane >> 5) == half) {
+    ma_f2* tb = reinterpret_cast<ma_f2*>(lds);
+    if (wave_needed) {
 #pragma unroll
-            for (int ch = 0; ch < 5; ch++)
-#pragma unroll
-                for (int r = 0; r < R; r++) lds[(ch * 32 + (lane & 31)) * TP + w * R + r] = hs[ch][r];
+        for (int r = 0; r < R; r++) {
+            const double g11 = hs[0][r], g12 = hs[1][r], g22 = hs[2][r], h1 = hs[3][r], h2 = hs[4][r];
+            const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            const float dx = (float)((g11 * h2 - g12 * h1) * idet);
+            const float dy = (float)((g22 * h1 - g12 * h2) * idet);
+            tb[lane * TP + w * R + r] = (ma_f2){dx, dy};
         }
-        __syncthreads();
-        for (int p = tid; p < 32 * TXW; p += NT) {
+    }
+    __syncthreads();
+
+    // Epilogue, lanes along x: every global access (R0, the R1 gather, M / flow stores) is coalesced.  Pixels right
+    // of / below the active extent are skipped: nothing reads M there (loads beyond the extent are replaced by 0)
+    // and the stitched flow ends with the image.
+    if (LAST) {
+        // centre crop of the window -> stitched flow (stitcher.py:62-65).  With reach == 0 the needed rectangle IS the
+        // crop clipped to the image (needed_rect_h), so membership needs no second test.  The flow is addressed
+        // through a buffer resource that starts at this block's first image row (offsets stay below 2^31 for any
+        // image the 32-bit pixel coordinates allow).
+        float* frow = flow_out + (size_t)(oy + y0) * g.t.W * 2;
+        const long long fbytes = (long long)min(64, yend - y0) * g.t.W * 8;
+        const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(
+            frow, 0, (int)(fbytes < 0x7fffffffLL ? fbytes : 0x7fffffffLL), 0x00020000);
+        for (int p = tid; p < 64 * TXW; p += NT) {
             const int rh = p / TXW, c = p - rh * TXW;
-            const int y = y0 + half * 32 + rh, x = x0 + c;
-            if (y < need.y1 && x >= need.x0 && x < need.x1) {
-                double g11 = lds[(0 * 32 + rh) * TP + c], g12 = lds[(1 * 32 + rh) * TP + c],
-                       g22 = lds[(2 * 32 + rh) * TP + c], h1 = lds[(3 * 32 + rh) * TP + c],
-                       h2 = lds[(4 * 32 + rh) * TP + c];
-                double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-                float dx = (float)((g11 * h2 - g12 * h1) * idet);
-                float dy = (float)((g22 * h1 - g12 * h2) * idet);
-                if (last) {
-                    // centre crop of the window -> stitched flow (stitcher.py:62-65)
-                    bool keep;
-                    if (g.t.T == 0) keep = true;
-                    else keep = y >= g.t.ov && y < g.t.ov + g.t.T && x >= g.t.ov && x < g.t.ov + g.t.T;
-                    int iy = oy + y, ix = ox + x;
-                    if (keep && iy < g.t.H && ix < g.t.W) {
-                        float2 v = make_float2(dx, dy);
-                        reinterpret_cast<float2*>(flow_out)[(size_t)iy * g.t.W + ix] = v;
-                    }
-                } else {
+            const int y = y0 + rh, x = x0 + c;
+            if (y < yend && x >= need.x0 && x < xend) {
+                const ma_f2 f = tb[rh * TP + c];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ma_u2, f), frsrc, (rh * g.t.W + ox + x) * 8, 0, 0);
+            }
+        }
+    } else {
+        auto epilogue = [&](auto near_border_tag) {
+            constexpr bool NEAR_BORDER = decltype(near_border_tag)::value;
+            for (int p = tid; p < 64 * TXW; p += NT) {
+                const int rh = p / TXW, c = p - rh * TXW;
+                const int y = y0 + rh, x = x0 + c;
+                if (y < yend && x >= need.x0 && x < xend) {
+                    const ma_f2 f = tb[rh * TP + c];
+                    const float dx = f.x, dy = f.y;
                     // UpdateMatrices (A.1 step 3) at this pixel
                     const int pix4 = (y * g.pitch + x) * 4;
                     float r0[5];
@@ -627,14 +649,17 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
                         }
                     }
                     float Mv[5];
-                    update_matrices_px(r0, r[0], r[1], r[2], r[3], r[4], inside, dx, dy, x, y, Pw, Ph, Mv);
+                    update_matrices_px<NEAR_BORDER>(r0, r[0], r[1], r[2], r[3], r[4], inside, dx, dy, x, y, Pw, Ph, Mv);
 #pragma unroll
                     for (int k = 0; k < 5; k++)
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Mv[k]), wrsrc, pix4, (PL_M + k) * plane4, 0);
                 }
             }
-        }
-        __syncthreads();
+        };
+        // the 5-px border attenuation of UpdateMatrices concerns only the outermost blocks of a window
+        const bool near_border = x0 < 5 || x0 + TXW > Pw - 5 || y0 < 5 || y0 + 64 > Ph - 5;
+        if (near_border) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
 }
 
@@ -818,7 +843,7 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
     const size_t lds_v = (size_t)(BV_NW * BV_R + 2 * m + 4) * 64 * sizeof(float);
     const int colsh = BH_NW * BH_R + 2 * m + 4;
     size_t lds_h = (size_t)64 * (colsh | 1) * sizeof(float);
-    const size_t lds_t = (size_t)5 * 32 * (BH_NW * BH_R + 1) * sizeof(float);
+    const size_t lds_t = (size_t)64 * (BH_NW * BH_R + 1) * 2 * sizeof(float);   // the flow on its way to the x-major epilogue
     if (lds_t > lds_h) lds_h = lds_t;
     const bool fast = m >= 1 && lds_v <= LDS_MAX && lds_h <= LDS_MAX && colsh <= 320;  // 320 = 5 chunks (winsize <= 253)
     // the LDS-staged kernels honour the active extent; the fallback kernels process whole windows
@@ -867,8 +892,13 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px_h[it]);
                 const long long items = (long long)((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R)) * ((Ph + 63) / 64) * ma_xcd_slots(nwin);
                 // Q = 64-column chunks of the staged row tile (112 + 2m + 4 columns)
-#define MA_BLUR_H(QQ) hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, QQ>), dim3(ma_xcd_grid(items)), dim3(64 * BH_NW), \
-                                         lds_h, ctx->stream, g, m, taps, ws, last, flow_out, nwin, reach)
+#define MA_BLUR_H(QQ)                                                                                               \
+    do {                                                                                                            \
+        if (last) hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, QQ, true>), dim3(ma_xcd_grid(items)),     \
+                                     dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, flow_out, nwin, reach);  \
+        else hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, QQ, false>), dim3(ma_xcd_grid(items)),         \
+                                dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, flow_out, nwin, reach);       \
+    } while (0)
                 if (colsh <= 192) MA_BLUR_H(3);
                 else if (colsh <= 256) MA_BLUR_H(4);
                 else MA_BLUR_H(5);

@@ -185,6 +185,7 @@ __device__ __forceinline__ void d_sym_fir_slide(const float* __restrict__ col, c
 // ST64 = false: element stride is 1 float  (row of an LDS tile)                 -> ds_read2_b32
 // Addressable range required from the caller: [jb - m - 1, jb + R + m].
 typedef float ma_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned ma_u2 __attribute__((ext_vector_type(2)));
 
 template <bool ST64, int O0, int O1>
 __device__ __forceinline__ ma_f2 d_lds_read_pair(unsigned addr)

@@ -849,8 +849,19 @@ int orc_minmax(const void* src, int dtype, size_t n, double* mn, double* mx)
     return ORC_OK;
 }
 
+/* Rounding models of the dog() chain (ORC_DOG_* flags).  OpenCV keeps GaussianBlur's separable filters
+ * (filter.simd.hpp: RowVec_32f, SymmColumnVec_32f) and convertTo's scale (convert_scale.simd.hpp: cvt_32f) in
+ * CPU-dispatched translation units.  The SSE2 baseline objects multiply then add; the AVX2 objects, which every
+ * x86-64 host with AVX2 + FMA3 selects at run time, are compiled with FMA3 and use fused multiply-adds
+ * (_mm256_fmadd_ps / v_fma, and the scalar tails contract the same way):
+ *   ORC_DOG_FUSED_BLUR   row filter  acc = fma(x_j, k_j, acc)  (left to right, first term k_0*x_0),
+ *                        column filter  acc = fma(a + b, k_j, acc)  (first term k_r*c)
+ *   ORC_DOG_FUSED_SCALE  both normalize() steps  dst = fma(src, a, b)
+ * flags == 0 is the SSE2 model, ORC_DOG_FUSED_BLUR | ORC_DOG_FUSED_SCALE the AVX2 one. */
+enum { ORC_DOG_FUSED_BLUR = 1, ORC_DOG_FUSED_SCALE = 2 };
+
 /* normalize(src, alpha=0, beta=1, NORM_MINMAX, CV_32F) */
-int orc_normalize_minmax_to_f32(const void* src, int dtype, size_t n, double alpha, double beta, float* dst)
+int orc_normalize_minmax_to_f32_ex(const void* src, int dtype, size_t n, double alpha, double beta, int fused, float* dst)
 {
     double smin, smax;
     int rc = orc_minmax(src, dtype, n, &smin, &smax);
@@ -863,14 +874,22 @@ int orc_normalize_minmax_to_f32(const void* src, int dtype, size_t n, double alp
 #pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (size_t i = 0; i < n; i++) {
         float v = load_as_f32(src, dtype, i);
-        float p = v * a;
-        dst[i] = p + b;
+        if (fused) {
+            dst[i] = fmaf(v, a, b);
+        } else {
+            float p = v * a;
+            dst[i] = p + b;
+        }
     }
     return ORC_OK;
 }
+int orc_normalize_minmax_to_f32(const void* src, int dtype, size_t n, double alpha, double beta, float* dst)
+{
+    return orc_normalize_minmax_to_f32_ex(src, dtype, n, alpha, beta, 0, dst);
+}
 
 /* normalize(src f32, 0, 255, NORM_MINMAX, CV_8U) */
-int orc_normalize_minmax_f32_to_u8(const float* src, size_t n, uint8_t* dst)
+int orc_normalize_minmax_f32_to_u8_ex(const float* src, size_t n, int fused, uint8_t* dst)
 {
     double smin, smax;
     int rc = orc_minmax(src, ORC_F32, n, &smin, &smax);
@@ -880,11 +899,20 @@ int orc_normalize_minmax_f32_to_u8(const float* src, size_t n, uint8_t* dst)
     float a = (float)scale, b = (float)shift;
 #pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (size_t i = 0; i < n; i++) {
-        float p = src[i] * a;
-        float v = p + b;
+        float v;
+        if (fused) {
+            v = fmaf(src[i], a, b);
+        } else {
+            float p = src[i] * a;
+            v = p + b;
+        }
         dst[i] = (uint8_t)clampi(cv_round_f(v), 0, 255);
     }
     return ORC_OK;
+}
+int orc_normalize_minmax_f32_to_u8(const float* src, size_t n, uint8_t* dst)
+{
+    return orc_normalize_minmax_f32_to_u8_ex(src, n, 0, dst);
 }
 
 /* getGaussianKernel(ksize, sigma, CV_32F), odd ksize, sigma > 0.  OpenCV 4.x
@@ -914,25 +942,34 @@ void orc_gaussian_kernel(int ksize, double sigma, float* k)
     free(v);
 }
 
-/* t[x] = t[x] + k*p[x]   and   d[x] = d[x] + k*(a[x] + b[x]): the line updates of the two GaussianBlur passes */
-ORC_CLONES static void gb_axpy(float* t, const float* p, float k, int n)
+/* t[x] = t[x] + k*p[x]   and   d[x] = d[x] + k*(a[x] + b[x]): the line updates of the two GaussianBlur passes
+ * (fused: one rounding per update) */
+ORC_CLONES static void gb_axpy(float* t, const float* p, float k, int n, int fused)
 {
-    for (int x = 0; x < n; x++) {
-        float v = k * p[x];
-        t[x] = t[x] + v;
+    if (fused) {
+        for (int x = 0; x < n; x++) t[x] = fmaf(k, p[x], t[x]);
+    } else {
+        for (int x = 0; x < n; x++) {
+            float v = k * p[x];
+            t[x] = t[x] + v;
+        }
     }
 }
-ORC_CLONES static void gb_axpy2(float* d, const float* a, const float* b, float k, int n)
+ORC_CLONES static void gb_axpy2(float* d, const float* a, const float* b, float k, int n, int fused)
 {
-    for (int x = 0; x < n; x++) {
-        float v = k * (a[x] + b[x]);
-        d[x] = d[x] + v;
+    if (fused) {
+        for (int x = 0; x < n; x++) d[x] = fmaf(k, a[x] + b[x], d[x]);
+    } else {
+        for (int x = 0; x < n; x++) {
+            float v = k * (a[x] + b[x]);
+            d[x] = d[x] + v;
+        }
     }
 }
 
 /* GaussianBlur(f32, (ksize,ksize), sigma), BORDER_REFLECT_101.  Row filter
  * (plain left-to-right accumulation) then symmetric column filter. */
-int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigma, float* dst)
+int orc_gaussian_blur_f32_ex(const float* src, int h, int w, int ksize, double sigma, int fused, float* dst)
 {
     if (h <= 0 || w <= 0 || ksize < 1 || !(ksize & 1)) return ORC_EINVAL;
     float* k = (float*)malloc(sizeof(float) * ksize);
@@ -958,7 +995,7 @@ int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigm
         for (int i = 0; i < pw; i++) pad[i] = s[reflect101(i - r, w)];
         const float k0 = k[0];
         for (int x = 0; x < w; x++) t[x] = k0 * pad[x];
-        for (int j = 1; j < ksize; j++) gb_axpy(t, pad + j, k[j], w);
+        for (int j = 1; j < ksize; j++) gb_axpy(t, pad + j, k[j], w, fused);
     }
     free(pad_all);
 #pragma omp parallel for schedule(static) num_threads(g_row_threads)
@@ -969,36 +1006,46 @@ int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigm
         for (int j = 1; j <= r; j++) {
             const float* a = tmp + (size_t)reflect101(y + j, h) * w;
             const float* b = tmp + (size_t)reflect101(y - j, h) * w;
-            gb_axpy2(d, a, b, k[r + j], w);
+            gb_axpy2(d, a, b, k[r + j], w, fused);
         }
     }
     free(k); free(tmp);
     return ORC_OK;
 }
 
+int orc_gaussian_blur_f32(const float* src, int h, int w, int ksize, double sigma, float* dst)
+{
+    return orc_gaussian_blur_f32_ex(src, h, w, ksize, sigma, 0, dst);
+}
+
 /* dog(img, True, low_sigma, high_sigma) of optflow_registrator.py:249-274 for a
- * non-all-zero input (the max()==0 shortcut is the caller's).  Output u8. */
-int orc_dog_u8(const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst)
+ * non-all-zero input (the max()==0 shortcut is the caller's).  Output u8.  flags: ORC_DOG_*. */
+int orc_dog_u8_ex(const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, int flags, uint8_t* dst)
 {
     size_t n = (size_t)h * w;
     float* fimg = (float*)malloc(sizeof(float) * n);
     float* ls = (float*)malloc(sizeof(float) * n);
     float* hs = (float*)malloc(sizeof(float) * n);
     int rc = ORC_OK;
+    const int fb = (flags & ORC_DOG_FUSED_BLUR) != 0, fs = (flags & ORC_DOG_FUSED_SCALE) != 0;
     if (!fimg || !ls || !hs) { rc = ORC_ENOMEM; goto done; }
-    rc = orc_normalize_minmax_to_f32(src, dtype, n, 0, 1, fimg);
+    rc = orc_normalize_minmax_to_f32_ex(src, dtype, n, 0, 1, fs, fimg);
     if (rc) goto done;
     int ksize = low_sigma * 4 * 2 + 1;
-    rc = orc_gaussian_blur_f32(fimg, h, w, ksize, low_sigma, ls);
+    rc = orc_gaussian_blur_f32_ex(fimg, h, w, ksize, low_sigma, fb, ls);
     if (rc) goto done;
-    rc = orc_gaussian_blur_f32(fimg, h, w, ksize, high_sigma, hs);
+    rc = orc_gaussian_blur_f32_ex(fimg, h, w, ksize, high_sigma, fb, hs);
     if (rc) goto done;
 #pragma omp parallel for schedule(static) num_threads(g_row_threads)
     for (size_t i = 0; i < n; i++) hs[i] = hs[i] - ls[i];
-    rc = orc_normalize_minmax_f32_to_u8(hs, n, dst);
+    rc = orc_normalize_minmax_f32_to_u8_ex(hs, n, fs, dst);
 done:
     free(fimg); free(ls); free(hs);
     return rc;
+}
+int orc_dog_u8(const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst)
+{
+    return orc_dog_u8_ex(src, dtype, h, w, low_sigma, high_sigma, 0, dst);
 }
 
 /* ------------------------------------------------------------------------- */

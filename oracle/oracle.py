@@ -64,6 +64,15 @@ def lib():
         _lib.orc_gaussian_kernel.argtypes = [C.c_int, C.c_double, C.c_void_p]
         _lib.orc_dog_u8.restype = C.c_int
         _lib.orc_dog_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        _lib.orc_normalize_minmax_to_f32_ex.restype = C.c_int
+        _lib.orc_normalize_minmax_to_f32_ex.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_double, C.c_double, C.c_int,
+                                                        C.c_void_p]
+        _lib.orc_normalize_minmax_f32_to_u8_ex.restype = C.c_int
+        _lib.orc_normalize_minmax_f32_to_u8_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        _lib.orc_gaussian_blur_f32_ex.restype = C.c_int
+        _lib.orc_gaussian_blur_f32_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        _lib.orc_dog_u8_ex.restype = C.c_int
+        _lib.orc_dog_u8_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         _lib.orc_nmi_u8.restype = C.c_int
         _lib.orc_nmi_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]
         _lib.orc_nmi_u8_chunks.restype = C.c_int
@@ -194,25 +203,31 @@ def pyr_up(img, dstsize=None):
 
 
 # --- cv2.normalize(.., NORM_MINMAX, ..) / cv2.GaussianBlur ---
-def normalize_minmax_f32(img, alpha=0.0, beta=1.0):
+# Rounding models of the dog() chain (ma_oracle.c, ORC_DOG_*): 0 = multiply then add (OpenCV's SSE2 baseline objects),
+# DOG_FUSED_BLUR | DOG_FUSED_SCALE = fused multiply-adds (the AVX2 + FMA3 objects an x86-64 host dispatches to).
+DOG_FUSED_BLUR, DOG_FUSED_SCALE = 1, 2
+DOG_FUSED = DOG_FUSED_BLUR | DOG_FUSED_SCALE
+
+
+def normalize_minmax_f32(img, alpha=0.0, beta=1.0, fused=False):
     img, dt = _img(img)
     dst = np.empty(img.shape, np.float32)
-    _check(lib().orc_normalize_minmax_to_f32(_p(img), dt, img.size, alpha, beta, _p(dst)), "normalize")
+    _check(lib().orc_normalize_minmax_to_f32_ex(_p(img), dt, img.size, alpha, beta, int(bool(fused)), _p(dst)), "normalize")
     return dst
 
 
-def normalize_minmax_u8(img):
+def normalize_minmax_u8(img, fused=False):
     img = np.ascontiguousarray(img, dtype=np.float32)
     dst = np.empty(img.shape, np.uint8)
-    _check(lib().orc_normalize_minmax_f32_to_u8(_p(img), img.size, _p(dst)), "normalize_u8")
+    _check(lib().orc_normalize_minmax_f32_to_u8_ex(_p(img), img.size, int(bool(fused)), _p(dst)), "normalize_u8")
     return dst
 
 
-def gaussian_blur(img, ksize, sigma):
+def gaussian_blur(img, ksize, sigma, fused=False):
     img = np.ascontiguousarray(img, dtype=np.float32)
     h, w = img.shape
     dst = np.empty_like(img)
-    _check(lib().orc_gaussian_blur_f32(_p(img), h, w, ksize, float(sigma), _p(dst)), "gaussian_blur")
+    _check(lib().orc_gaussian_blur_f32_ex(_p(img), h, w, ksize, float(sigma), int(bool(fused)), _p(dst)), "gaussian_blur")
     return dst
 
 
@@ -222,8 +237,8 @@ def gaussian_kernel(ksize, sigma):
     return k
 
 
-def dog(img, use_it=True, low_sigma=5, high_sigma=9):
-    """OptFlowRegistrator.dog (optflow_registrator.py:249-274) incl. the max()==0 shortcut."""
+def dog(img, use_it=True, low_sigma=5, high_sigma=9, flags=0):
+    """OptFlowRegistrator.dog (optflow_registrator.py:249-274) incl. the max()==0 shortcut.  flags: DOG_FUSED_*."""
     if not use_it:
         return img
     if img.max() == 0:
@@ -231,7 +246,7 @@ def dog(img, use_it=True, low_sigma=5, high_sigma=9):
     img, dt = _img(img)
     h, w = img.shape
     dst = np.empty((h, w), np.uint8)
-    _check(lib().orc_dog_u8(_p(img), dt, h, w, low_sigma, high_sigma, _p(dst)), "dog")
+    _check(lib().orc_dog_u8_ex(_p(img), dt, h, w, low_sigma, high_sigma, int(flags), _p(dst)), "dog")
     return dst
 
 

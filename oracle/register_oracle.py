@@ -130,10 +130,11 @@ def upscale_to_full(flow, factor, full_shape):
 
 # ---- optflow_registrator.py:93-173 --------------------------------------------------------------------
 def register(ref, mov, num_pyr_lvl=4, num_iterations=3, tile_size=1000, overlap=100, use_full_res_img=False,
-             use_dog=False, fused=False, nthreads=1, stage_seconds=None):
+             use_dog=False, fused=False, nthreads=1, stage_seconds=None, dog_flags=0):
     """Returns (flow, reports); reports = [(factor, mi_after, mi_before, accepted), ...].
     stage_seconds: optional dict that receives the wall seconds per stage (pyramid, dog, farneback, warp, nmi,
-    merge_pyrup)."""
+    merge_pyrup).  fused: window blur of Farneback with FMA; dog_flags: rounding model of the dog() chain
+    (oracle.DOG_FUSED_*)."""
     win = overlap - (1 - overlap % 2)
     O.set_threads(nthreads)  # rows / NMI chunks / Farneback windows fan out over host threads; same bits for any count
     T = stage_seconds
@@ -149,7 +150,7 @@ def register(ref, mov, num_pyr_lvl=4, num_iterations=3, tile_size=1000, overlap=
             with _stage(T, "warp"):
                 mov_lvl = warp(mov_lvl, m_flow, tile_size, overlap)
         with _stage(T, "dog"):
-            fb_ref, fb_mov = O.dog(ref_pyr[lvl], use_dog), O.dog(mov_lvl, use_dog)
+            fb_ref, fb_mov = O.dog(ref_pyr[lvl], use_dog, flags=dog_flags), O.dog(mov_lvl, use_dog, flags=dog_flags)
         with _stage(T, "farneback"):
             this_flow = tile_flow(fb_ref, fb_mov, tile_size, overlap, win, num_iterations, fused=fused,
                                   nthreads=nthreads)
@@ -157,7 +158,8 @@ def register(ref, mov, num_pyr_lvl=4, num_iterations=3, tile_size=1000, overlap=
         with _stage(T, "warp"):
             warped = warp(mov_lvl, this_flow, tile_size, overlap)
         with _stage(T, "dog"):
-            ref_d, warped_d, raw_d = O.dog(ref_pyr[lvl], True), O.dog(warped, True), O.dog(mov_pyr[lvl], True)
+            ref_d, warped_d, raw_d = (O.dog(ref_pyr[lvl], True, flags=dog_flags), O.dog(warped, True, flags=dog_flags),
+                                     O.dog(mov_pyr[lvl], True, flags=dog_flags))
         with _stage(T, "nmi"):
             after = mi_tiled(ref_d, warped_d, tile_size)
             before = mi_tiled(ref_d, raw_d, tile_size)
