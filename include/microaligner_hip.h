@@ -52,6 +52,15 @@ enum ma_farneback_flags {
                               v_muladd is an FMA); default is multiply-then-add (x86 SSE baseline) */
 };
 
+/* flags for ma_dog_u8_ex: rounding model of the dog() chain.  OpenCV keeps GaussianBlur's separable filters
+ * (filter.simd.hpp) and cv2.normalize's scaling (convert_scale.simd.hpp) in CPU-dispatched objects: the SSE2
+ * baseline multiplies then adds (flags 0, the default of every other entry point), the AVX2 + FMA3 objects that an
+ * x86-64 host with AVX2 selects at run time use fused multiply-adds (both flags). */
+enum ma_dog_flags {
+    MA_DOG_FUSED_BLUR = 1, /* row filter acc = fma(x_j, k_j, acc); column filter acc = fma(a + b, k_j, acc) */
+    MA_DOG_FUSED_SCALE = 2 /* both normalize() steps: dst = fma(src, a, b) */
+};
+
 /* ---- library / context ------------------------------------------------- */
 const char* ma_version(void);
 const char* ma_last_error(void);
@@ -216,6 +225,11 @@ int ma_warp_tiled_minmax(ma_ctx* ctx, const void* img, int dtype, int H, int W, 
 int ma_pyr_down_minmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst, float* minmax_dev);
 int ma_dog_u8_minmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma,
                      const float* src_minmax_dev, uint8_t* dst, int* src_max_is_zero_host);
+
+/* ma_dog_u8 / ma_dog_u8_minmax with the rounding model as a parameter (enum ma_dog_flags); src_minmax_dev may be
+ * NULL (the image is reduced first).  Replaces the same call sites: optflow_registrator.py:259-274. */
+int ma_dog_u8_ex(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, int flags,
+                 const float* src_minmax_dev, uint8_t* dst, int* src_max_is_zero_host);
 
 /* cv2.warpAffine(src, M, dsize=(dw, dh)) with the default flags (INTER_LINEAR, BORDER_CONSTANT 0), the call of
  * FeatureRegistrator.transform_img (feature_reg/feature_registrator.py:128-132) for images up to 32000 px.

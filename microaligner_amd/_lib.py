@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmicroaligner_hip.so")
 MA_U8, MA_U16, MA_F32 = 0, 1, 2
 MA_OK, MA_EINVAL, MA_ENOMEM, MA_EHIP, MA_ENODEV = 0, -1, -2, -3, -4
 MA_FB_MULADD_FUSED = 1
+MA_DOG_FUSED_BLUR, MA_DOG_FUSED_SCALE = 1, 2
 MA_FLOW_CELL_REPLICAS = 8
 
 KERNEL_IDS = {"polyexp_m0": 0, "blur_v": 1, "blur_h_solve": 2, "warp": 3, "merge": 4, "pyr_down": 5,
@@ -64,6 +65,7 @@ SIGNATURES = {
     "ma_merge_flows_tiled_cells": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "ma_pyr_down_minmax": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ma_dog_u8_minmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
+    "ma_dog_u8_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "ma_warp_affine_cv": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _i, _i, _vp]),
     "ma_knn2_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "ma_fast_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

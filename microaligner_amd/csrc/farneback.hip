@@ -414,13 +414,21 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v_stream(FbGeom g, 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0,
                                                                            (int)(g.plane * sizeof(float)), 0x00020000);
     const __amdgpu_buffer_rsrc_t drsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)(g.plane * sizeof(float)), 0x00020000);
+    // Loads are unconditional and their results are used unconditionally: beyond the active extent (where M is
+    // exactly zero and was never written) the row is clamped into the extent and the value is masked to +0 when it
+    // is committed to LDS, a chunk later.  (Written as `if (beyond) val = 0` next to the load, the compiler makes the
+    // load itself conditional and waits for every single one right where it is issued -- fourteen dependent round
+    // trips in front of the filter instead of one hidden behind it: 0.3 ms per launch, profiles/r03_notes.md.)
     auto load_row = [&](int v) -> float {    // virtual row v = window row ybase + v, replicated at the window border
         const int y = d_clamp(ybase + v, 0, Ph - 1);
-        float val = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xo, min(y, ey - 1) * g.pitch * 4, 0));
-        if (y >= ey || !xin) val = 0.f;      // beyond the active extent M is exactly zero (and was not written)
-        return val;
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xo, min(y, ey - 1) * g.pitch * 4, 0));
     };
-    auto commit_row = [&](int pos, float val) {   // pos: ring row, 0 <= pos < C
+    const unsigned lanemask = xin ? 0xffffffffu : 0u;
+    auto row_mask = [&](int v) -> unsigned {  // wave-uniform: all ones unless virtual row v lies below the active extent
+        return d_clamp(ybase + v, 0, Ph - 1) >= ey ? 0u : 0xffffffffu;
+    };
+    auto commit_row = [&](int pos, float val, unsigned rmask) {   // pos: ring row, 0 <= pos < C
+        val = __uint_as_float(__float_as_uint(val) & (lanemask & rmask));
         lds[pos * 64 + lane] = val;
         if (pos < MIR) lds[(pos + C) * 64 + lane] = val;
     };
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v_stream(FbGeom g, 
             for (int k = 0; k < SB; k++) v[k] = load_row(min(j0 + NW * k, npro - 1));
 #pragma unroll
             for (int k = 0; k < SB; k++)
-                if (j0 + NW * k < npro) commit_row(j0 + NW * k, v[k]);
+                if (j0 + NW * k < npro) commit_row(j0 + NW * k, v[k], row_mask(j0 + NW * k));
         }
     }
     float nv[R];                              // the NW*R new rows of the coming chunk, R per wave
@@ -449,7 +457,7 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v_stream(FbGeom g, 
         for (int k = 0; k < R; k++) {
             int p = pnew + w + NW * k;
             if (p >= C) p -= C;
-            commit_row(p, nv[k]);
+            commit_row(p, nv[k], row_mask(vnew + w + NW * k));
         }
         __syncthreads();
         vnew += CH;

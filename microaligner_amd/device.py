@@ -405,19 +405,17 @@ class Context:
         self._run(self.lib.ma_minmax, arr.ptr, _dt(arr.dtype), arr.size, C.byref(mn), C.byref(mx))
         return mn.value, mx.value
 
-    def dog_u8(self, img, low_sigma=5, high_sigma=9, report_zero=False):
+    def dog_u8(self, img, low_sigma=5, high_sigma=9, report_zero=False, flags=0):
         """Body of OptFlowRegistrator.dog -> uint8.  Stream ordered (no host sync) unless report_zero, in which
-        case (out, src_max_is_zero) is returned; out is all zero when the input's max is 0."""
+        case (out, src_max_is_zero) is returned; out is all zero when the input's max is 0.
+        flags: rounding model of the chain (MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE, include/microaligner_hip.h)."""
         h, w = img.shape
         out = self.empty((h, w), np.uint8)
         flag = C.c_int(0)
         fl = C.byref(flag) if report_zero else None
-        if img.minmax is not None:   # the producing kernel already reduced the image
-            self._run(self.lib.ma_dog_u8_minmax, img.ptr, _dt(img.dtype), h, w, int(low_sigma),
-                                              int(high_sigma), img.minmax.ptr, out.ptr, fl)
-        else:
-            self._run(self.lib.ma_dog_u8, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma),
-                                       out.ptr, fl)
+        # img.minmax: the producing kernel already reduced the image
+        self._run(self.lib.ma_dog_u8_ex, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma), int(flags),
+                  img.minmax.ptr if img.minmax is not None else None, out.ptr, fl)
         return (out, bool(flag.value)) if report_zero else out
 
     def nmi_scores(self, a, b, chunk=0):

@@ -15,6 +15,7 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
+from .. import _lib as L
 from ..device import DeviceArray, get_context
 from ..shared_modules.img_checks import check_img_dims_match, check_img_is_2d_grey, check_img_is_provided
 from ..shared_modules.similarity_scoring import mi_tiled
@@ -54,6 +55,9 @@ class OptFlowRegistrator:
         # additions (defaults keep the reference's behaviour)
         self.verbose = True            # the reference prints per-level progress
         self.muladd_fused = False      # window blur with FMA (see MA_FB_MULADD_FUSED)
+        # dog() chain (GaussianBlur, normalize) with fused multiply-adds: what OpenCV's AVX2 + FMA3 objects compute
+        # (MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE); default: the SSE2 baseline arithmetic
+        self.dog_muladd_fused = False
         self.level_reports: List[LevelReport] = []
         self._warper = Warper()
         self._tile_flow_calc = TileFlowCalc()
@@ -228,14 +232,19 @@ class OptFlowRegistrator:
         """dog(img, True) for register(): stays on the stream.  Where the reference returns an image whose max
         is 0 unchanged (:256-257) this yields the all-zero uint8 image, which every consumer on the path
         (Farneback's convertTo float, the NMI labels) treats identically for the all-zero image that case means."""
-        return get_context().dog_u8(img, low_sigma, high_sigma)
+        return get_context().dog_u8(img, low_sigma, high_sigma, flags=self._dog_flags())
+
+    def _dog_flags(self) -> int:
+        f = self.dog_muladd_fused
+        return int(f) if isinstance(f, int) and not isinstance(f, bool) else (L.MA_DOG_FUSED_BLUR | L.MA_DOG_FUSED_SCALE if f else 0)
 
     def dog(self, img, use_it: bool, low_sigma: int = 5, high_sigma: int = 9):
         """Difference of Gaussians -> uint8 (optflow_registrator.py:249-274)."""
         if not use_it:
             return img
         ctx = get_context()
-        out, src_max_is_zero = ctx.dog_u8(ctx.asdevice(img), low_sigma, high_sigma, report_zero=True)
+        out, src_max_is_zero = ctx.dog_u8(ctx.asdevice(img), low_sigma, high_sigma, report_zero=True,
+                                          flags=self._dog_flags())
         if src_max_is_zero:
             return img
         return out if isinstance(img, DeviceArray) else out.numpy()

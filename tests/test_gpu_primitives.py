@@ -286,6 +286,25 @@ def test_dog_other_sigmas_bit_exact(ctx, sigmas):
     assert np.array_equal(ctx.dog_u8(ctx.asdevice(img), *sigmas).numpy(), exp)
 
 
+@pytest.mark.parametrize("flags", [O.DOG_FUSED_BLUR, O.DOG_FUSED_SCALE, O.DOG_FUSED])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+def test_dog_fused_rounding_models_bit_exact(ctx, dtype, flags):
+    """The dog() chain in the rounding models of OpenCV's AVX2 + FMA3 objects (fused multiply-adds in the two
+    GaussianBlur passes and / or in the two normalize() steps): oracle and kernels agree bit for bit in every
+    combination, for the fused kernel (sigmas 5 / 9) and for the two-kernel chain (other sigmas); the models differ
+    from the default by at most one grey level."""
+    img, _ = pair(301, 453, seed=21 + flags, dtype=dtype)
+    d = ctx.asdevice(img)
+    exp = O.dog(img, True, flags=flags)
+    got = ctx.dog_u8(d, flags=flags).numpy()
+    assert np.array_equal(got, exp)
+    assert np.abs(got.astype(np.int16) - O.dog(img, True).astype(np.int16)).max() <= 1
+    for sigmas in ((3, 5), (6, 9)):
+        assert np.array_equal(ctx.dog_u8(d, *sigmas, flags=flags).numpy(), O.dog(img, True, *sigmas, flags=flags))
+    with pytest.raises(ValueError):
+        ctx.dog_u8(d, flags=4)
+
+
 @pytest.mark.parametrize("shape", [(70, 1030), (33, 1024), (9, 517)])
 def test_dog_wide_rows_bit_exact(ctx, shape):
     """Several 256-column blocks per row, widths that are and are not multiples of 4."""

@@ -73,6 +73,25 @@ def test_register_matches_oracle_orchestration(shape, dtype, params):
     assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("dog_fused,fb_fused", [(True, False), (True, True)])
+def test_register_in_the_fused_rounding_models_matches_the_oracle(dog_fused, fb_fused):
+    """register() with the dog() chain (and the Farneback window blur) in the fused multiply-add models -- what an
+    OpenCV build dispatching to its AVX2 + FMA3 objects (and one whose v_muladd is an FMA) computes: same gate
+    decisions, same MI scores, same flow as the oracle orchestration in the same model."""
+    from oracle import oracle as O
+    params = dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True, tile_size=160, overlap=30)
+    ref, mov = synthetic.make_pair(600, 520, seed=33)
+    exp, reports = RO.register(ref, mov, fused=fb_fused, dog_flags=O.DOG_FUSED if dog_fused else 0, **params)
+    reg = make_reg(dict(params, dog_muladd_fused=dog_fused, muladd_fused=fb_fused))
+    reg.ref_img, reg.mov_img = ref, mov
+    got = reg.register()
+    assert [r.accepted for r in reg.level_reports] == [r[3] for r in reports]
+    np.testing.assert_allclose([(r.mi_after, r.mi_before) for r in reg.level_reports], [r[1:3] for r in reports],
+                               rtol=0, atol=1e-12)
+    assert np.array_equal(got, exp)
+    assert np.array_equal(reg.dog(ref, True), O.dog(ref, True, flags=O.DOG_FUSED if dog_fused else 0))
+
+
 def test_device_resident_inputs_stay_on_device(ctx):
     ref, mov = synthetic.make_pair(420, 404, 1)
     reg = make_reg(dict(num_pyr_lvl=2, use_full_res_img=True, tile_size=100, overlap=20))

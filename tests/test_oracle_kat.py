@@ -192,6 +192,60 @@ def test_gaussian_blur_matches_scipy_correlate():
     np.testing.assert_allclose(O.gaussian_blur(img, 41, 5), exp, atol=2e-6)
 
 
+def _round_f32(fr):
+    """Correctly rounded float32 of an exact rational (round to nearest, ties to even)."""
+    from fractions import Fraction
+    c = np.float32(float(fr))
+    cands = {float(c), float(np.nextafter(c, np.float32(np.inf))), float(np.nextafter(c, np.float32(-np.inf)))}
+    def key(v):
+        even = (np.float32(v).view(np.uint32) & 1) == 0
+        return (abs(Fraction(v) - fr), 0 if even else 1)
+    return np.float32(min(cands, key=key))
+
+
+def test_gaussian_blur_fused_model_is_one_rounding_per_tap():
+    """The fused rounding model (ORC_DOG_FUSED_BLUR): row filter acc = fma(k_j, x_j, acc) left to right, column filter
+    acc = fma(k_j, a + b, acc) outward from the centre -- checked against exact rational arithmetic with one
+    correctly rounded float32 result per tap, on a small image (pure-Python loops)."""
+    from fractions import Fraction as F
+    rng = np.random.default_rng(3)
+    img = rng.random((7, 9)).astype(np.float32)
+    ks, sigma = 5, 1.0
+    k = O.gaussian_kernel(ks, sigma)
+    r = ks // 2
+    refl = lambda p, n: -p if p < 0 else (2 * n - 2 - p if p >= n else p)   # noqa: E731  (BORDER_REFLECT_101)
+    h, w = img.shape
+    rows = np.empty_like(img)
+    for y in range(h):
+        for x in range(w):
+            acc = np.float32(k[0]) * img[y, refl(x - r, w)]
+            for j in range(1, ks):
+                acc = _round_f32(F(float(k[j])) * F(float(img[y, refl(x - r + j, w)])) + F(float(acc)))
+            rows[y, x] = acc
+    exp = np.empty_like(img)
+    for y in range(h):
+        for x in range(w):
+            acc = np.float32(k[r]) * rows[y, x]
+            for j in range(1, r + 1):
+                s = rows[refl(y + j, h), x] + rows[refl(y - j, h), x]     # float32 add, rounded
+                acc = _round_f32(F(float(k[r + j])) * F(float(s)) + F(float(acc)))
+            exp[y, x] = acc
+    got = O.gaussian_blur(img, ks, sigma, fused=True)
+    assert np.array_equal(got, exp)
+    assert not np.array_equal(got, O.gaussian_blur(img, ks, sigma))     # the models do differ in the last bit
+
+
+def test_dog_rounding_models_differ_by_at_most_one_grey_level():
+    img, _ = synthetic.make_pair(300, 280, 5)
+    base = O.dog(img).astype(np.int16)
+    for flags in (O.DOG_FUSED_BLUR, O.DOG_FUSED_SCALE, O.DOG_FUSED):
+        d = np.abs(O.dog(img, flags=flags).astype(np.int16) - base)
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+    f = O.normalize_minmax_f32(img, fused=True)
+    assert abs(f.min()) < 1e-7 and abs(f.max() - 1.0) < 1e-6   # fma(smin, a, -round(smin*a)) is the rounding residual, not 0
+    assert np.abs(f - O.normalize_minmax_f32(img)).max() < 2e-7
+
+
 # ---- NMI: pinned against the installed scikit-learn ---------------------------------------------------
 def test_nmi_matches_sklearn():
     from sklearn.metrics import normalized_mutual_info_score as nmi
