@@ -72,6 +72,12 @@ int ma_sync(ma_ctx* ctx);
 int ma_ctx_set_workspace_limit(ma_ctx* ctx, size_t bytes);
 /* The ctx's hipStream_t as an opaque pointer (for event timing by the caller). */
 void* ma_ctx_stream(ma_ctx* ctx);
+/* Returns the device buffers the ctx caches for the intermediates of ma_optflow_register to the driver (synchronises). */
+int ma_ctx_trim(ma_ctx* ctx);
+/* Bytes moved so far by the explicit host <-> device copies of this ctx (ma_memcpy_h2d / _d2h / _d2h_async and the
+ * page transfers of ma_warp_pages_host); reset != 0 clears the counters after reading.  Lets a caller (and the tests)
+ * check that a loop such as warp_and_save_pages (__main__.py:288-302) uploads its flow once, not once per page. */
+int ma_ctx_transfer_stats(ma_ctx* ctx, unsigned long long* h2d_bytes, unsigned long long* d2h_bytes, int reset);
 
 /* ---- device memory (caller owns host buffers; library owns nothing it returns
  *      except the error string) ------------------------------------------- */
@@ -131,6 +137,45 @@ int ma_farneback_tiled(ma_ctx* ctx, const void* prev, const void* next, int dtyp
 int ma_farneback_debug(ma_ctx* ctx, const void* prev, const void* next, int dtype, int H, int W,
                        int winsize, int iterations, double poly_sigma, int flags, float* flow_out,
                        float* R0_planar, float* R1_planar, float* M0_planar);
+
+/* ---- the whole of OptFlowRegistrator.register() ------------------------------------------------
+ * Replaces the level loop of microaligner/optflow_reg/optflow_registrator.py:93-173 (with _generate_img_pyr
+ * :175-202, _upscale_flow_to_full_res :204-215, _merge_list_of_flows :235-240 and the mutual-information gate of
+ * shared_modules/similarity_scoring.py:27-68): Gaussian pyramid of both images, and per level, smallest first,
+ * warp by the flow so far -> dog() -> tiled Farneback -> warp -> dog() x 2 -> NMI gate -> merge / pyrUp or the
+ * reject branch, including the reference's quirks (merge in absolute coordinates; no doubling when the result is
+ * upscaled to full resolution; x4 in the middle-level reject branch).  ma_params carries the attributes of the
+ * reference's class (optflow_registrator.py:54-59) plus the two rounding-model flag sets of this library.
+ *
+ * ref, mov: (H, W) device images of `dtype`; flow_out: (H, W, 2) float32 device buffer owned by the caller, with
+ * mov(p) ~ ref(p + flow(p)).  reports (may be NULL): one record per pyramid level, smallest level first -- what the
+ * reference prints (factor, MI scores, accept / reject); *n_reports receives the number of levels.  The call
+ * synchronises the ctx stream once per level (the gate decision needs the NMI scores on the host); on return the
+ * flow is enqueued, not necessarily complete (ma_sync).  MA_EINVAL when the pyramid would be empty: where the
+ * reference dies with an UnboundLocalError (:173). */
+typedef struct ma_params {
+    int num_pyr_lvl;      /* 4    */
+    int num_iterations;   /* 3    */
+    int tile_size;        /* 1000 */
+    int overlap;          /* 100: also sets the Farneback window, the largest odd number <= overlap (:91) */
+    int use_full_res_img; /* 0    */
+    int use_dog;          /* 0    */
+    int fb_flags;         /* enum ma_farneback_flags */
+    int dog_flags;        /* enum ma_dog_flags */
+} ma_params;
+typedef struct ma_level_report {
+    int factor;           /* pyramid factor of the level: 2^k, 1 = full resolution */
+    int h, w;             /* level shape */
+    double mi_after;      /* mean NMI(dog(ref), dog(warped moving image)) */
+    double mi_before;     /* mean NMI(dog(ref), dog(raw moving level)) */
+    int accepted;         /* mi_after > mi_before */
+} ma_level_report;
+void ma_params_default(ma_params* p); /* the defaults of OptFlowRegistrator.__init__ (:54-59), flags 0 */
+int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype, int H, int W, const ma_params* params,
+                        float* flow_out, ma_level_report* reports, int max_reports, int* n_reports);
+/* np.mean of a contiguous float64 vector exactly as numpy evaluates it (pairwise sum, one division): the reduction mi_tiled applies to the chunk scores (similarity_scoring.py:49).  Host-only helper,
+ * exported so that the gate arithmetic of ma_optflow_register can be checked against numpy without a GPU. */
+int ma_host_np_mean(const double* v, long n, double* out);
 
 /* ---- remap / warp --------------------------------------------------------
  * ma_remap_bilinear replaces cv2.remap(src, map, None, cv2.INTER_LINEAR)

@@ -73,6 +73,28 @@ SIGNATURES = {
                                _vp, _vp, _i, _vp]),
 }
 
+
+
+class MaParams(C.Structure):
+    """ma_params of include/microaligner_hip.h."""
+    _fields_ = [("num_pyr_lvl", _i), ("num_iterations", _i), ("tile_size", _i), ("overlap", _i), ("use_full_res_img", _i),
+                ("use_dog", _i), ("fb_flags", _i), ("dog_flags", _i)]
+
+
+class MaLevelReport(C.Structure):
+    """ma_level_report of include/microaligner_hip.h."""
+    _fields_ = [("factor", _i), ("h", _i), ("w", _i), ("mi_after", _d), ("mi_before", _d), ("accepted", _i)]
+
+
+SIGNATURES.update({
+    "ma_ctx_trim": (_i, [_vp]),
+    "ma_ctx_transfer_stats": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _i]),
+    "ma_params_default": (None, [C.POINTER(MaParams)]),
+    "ma_optflow_register": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(MaParams), _vp, C.POINTER(MaLevelReport), _i,
+                                 C.POINTER(_i)]),
+    "ma_host_np_mean": (_i, [C.POINTER(_d), C.c_long, C.POINTER(_d)]),
+})
+
 _lib = None
 
 

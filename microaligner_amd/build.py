@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmicroaligner_hip.so")
-SOURCES = ["ma_api.hip", "farneback.hip", "remap.hip", "pyramid.hip", "dog.hip", "nmi.hip", "affine.hip", "knn.hip", "daisy.hip"]
+SOURCES = ["ma_api.hip", "farneback.hip", "remap.hip", "pyramid.hip", "dog.hip", "nmi.hip", "affine.hip", "knn.hip", "daisy.hip", "register.hip"]
 HEADERS = [os.path.join(CSRC, "ma_internal.h"), os.path.join(HERE, "..", "include", "microaligner_hip.h")]
 # -fno-slp-vectorize: the SLP vectoriser packs the sliding-window blur into v_pk_* ops with a storm of
 # register-pair shuffles (measured 1.65x slower on blur_h_solve, profiles/r01_*); packed math is written by hand

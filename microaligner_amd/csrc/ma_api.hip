@@ -67,6 +67,8 @@ void ma_ctx_destroy(ma_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& r : ctx->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : ctx->free_events) (void)hipEventDestroy(e);
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->dconst) (void)hipFree(ctx->dconst);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -90,6 +92,25 @@ int ma_ctx_set_workspace_limit(ma_ctx* ctx, size_t bytes)
 }
 
 void* ma_ctx_stream(ma_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ma_ctx_trim(ma_ctx* ctx)
+{
+    MA_REQUIRE(ctx, "ctx is NULL");
+    MA_HIP(hipSetDevice(ctx->device));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+    ctx->pool_free.clear();
+    return MA_OK;
+}
+
+int ma_ctx_transfer_stats(ma_ctx* ctx, unsigned long long* h2d_bytes, unsigned long long* d2h_bytes, int reset)
+{
+    MA_REQUIRE(ctx, "ctx is NULL");
+    if (h2d_bytes) *h2d_bytes = ctx->h2d_bytes;
+    if (d2h_bytes) *d2h_bytes = ctx->d2h_bytes;
+    if (reset) ctx->h2d_bytes = ctx->d2h_bytes = 0;
+    return MA_OK;
+}
 
 int ma_malloc(ma_ctx* ctx, size_t bytes, void** dptr)
 {
@@ -119,6 +140,7 @@ int ma_memcpy_h2d(ma_ctx* ctx, void* dst, const void* src_host, size_t bytes)
 {
     MA_REQUIRE(ctx && (bytes == 0 || (dst && src_host)), "NULL argument");
     if (!bytes) return MA_OK;
+    ctx->h2d_bytes += bytes;
     MA_HIP(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     // pageable host memory: the async copy is staged, return only when the source may be reused
     MA_HIP(hipStreamSynchronize(ctx->stream));
@@ -129,6 +151,7 @@ int ma_memcpy_d2h(ma_ctx* ctx, void* dst_host, const void* src, size_t bytes)
 {
     MA_REQUIRE(ctx && (bytes == 0 || (dst_host && src)), "NULL argument");
     if (!bytes) return MA_OK;
+    ctx->d2h_bytes += bytes;
     MA_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));
     return MA_OK;
@@ -138,6 +161,7 @@ int ma_memcpy_d2h_async(ma_ctx* ctx, void* dst_host, const void* src, size_t byt
 {
     MA_REQUIRE(ctx && (bytes == 0 || (dst_host && src)), "NULL argument");
     if (!bytes) return MA_OK;
+    ctx->d2h_bytes += bytes;
     MA_HIP(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return MA_OK;
 }
@@ -300,6 +324,42 @@ int ma_pinned_reserve(ma_ctx* ctx, size_t bytes)
 int ma_dconst_reserve(ma_ctx* ctx, size_t bytes)
 {
     return reserve(&ctx->dconst, &ctx->dconst_bytes, ma_align_up(bytes, 4096), false, ctx);
+}
+
+void* ma_pool_alloc(ma_ctx* ctx, size_t bytes)
+{
+    const size_t bucket = ma_align_up(bytes ? bytes : 1, (size_t)1 << 16);
+    auto it = ctx->pool_free.find(bucket);
+    void* p = nullptr;
+    if (it != ctx->pool_free.end()) {
+        p = it->second;
+        ctx->pool_free.erase(it);
+    } else {
+        hipError_t e = hipMalloc(&p, bucket);
+        if (e == hipErrorOutOfMemory && !ctx->pool_free.empty()) {
+            // hand the cached buffers of other sizes back and try once more
+            (void)hipStreamSynchronize(ctx->stream);
+            for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+            ctx->pool_free.clear();
+            e = hipMalloc(&p, bucket);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            ma_set_error("hipMalloc(%zu) failed: %s", bucket, hipGetErrorString(e));
+            return nullptr;
+        }
+    }
+    ctx->pool_live[p] = bucket;
+    return p;
+}
+
+void ma_pool_free(ma_ctx* ctx, void* p)
+{
+    if (!p) return;
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) return;
+    ctx->pool_free.emplace(it->second, p);
+    ctx->pool_live.erase(it);
 }
 
 static std::mutex g_table_mutex;

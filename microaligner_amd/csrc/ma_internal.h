@@ -5,7 +5,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -57,7 +59,21 @@ struct ma_ctx {
     double prof_ms[MA_K_COUNT] = {0};
     long long prof_n[MA_K_COUNT] = {0};
     double prof_px[MA_K_COUNT] = {0};
+    // size-bucketed cache of device buffers for the intermediates of ma_optflow_register (pyramids, DOG images, flows):
+    // stream-ordered reuse on the ctx stream, returned to the driver by ma_ctx_trim / ma_ctx_destroy
+    std::multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_live;
+    // bytes moved by the explicit host <-> device copies of this ctx (ma_memcpy_*, ma_warp_pages_host)
+    unsigned long long h2d_bytes = 0, d2h_bytes = 0;
 };
+
+// device buffer from the ctx cache (64 KiB buckets); nullptr + error set on failure
+void* ma_pool_alloc(ma_ctx* ctx, size_t bytes);
+void ma_pool_free(ma_ctx* ctx, void* p);
+// NMI of consecutive chunks, enqueue only: scores land in scores_pinned_host (page-locked) once the ctx stream has
+// passed this point (nmi.hip)
+int ma_nmi_u8_enqueue(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk, double* scores_pinned_host,
+                      int max_scores, int* n_scores);
 
 int ma_ws_reserve(ma_ctx* ctx, size_t bytes);      // ensures ctx->ws has >= bytes
 int ma_pinned_reserve(ma_ctx* ctx, size_t bytes);

@@ -158,12 +158,10 @@ __global__ __launch_bounds__(NR_T) void nmi_reduce_kernel(const unsigned* __rest
 
 } // namespace
 
-extern "C" {
-
-int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk, double* scores_host,
-              int max_scores, int* n_scores)
+int ma_nmi_u8_enqueue(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk, double* scores_pinned_host,
+                      int max_scores, int* n_scores)
 {
-    MA_REQUIRE(ctx && a && b && scores_host && n_scores, "NULL argument");
+    MA_REQUIRE(ctx && a && b && scores_pinned_host && n_scores, "NULL argument");
     MA_REQUIRE(n > 0, "empty arrays");
     if (chunk == 0 || chunk > n) chunk = n;
     const size_t nchunks = (n + chunk - 1) / chunk;
@@ -173,7 +171,6 @@ int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t 
     const size_t hist_bytes = nchunks * 65536 * sizeof(unsigned);
     const size_t total = hist_bytes + nchunks * sizeof(double);
     MA_TRY(ma_ws_reserve(ctx, total));
-    MA_TRY(ma_pinned_reserve(ctx, nchunks * sizeof(double)));
     unsigned* hist = (unsigned*)ctx->ws;
     double* scores = (double*)((char*)ctx->ws + hist_bytes);
     {
@@ -186,10 +183,23 @@ int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t 
         hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)nchunks), dim3(NR_T), 0, ctx->stream, hist, n, chunk, scores);
         MA_HIP(hipGetLastError());
     }
-    MA_HIP(hipMemcpyAsync(ctx->pinned, scores, nchunks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i < nchunks; i++) scores_host[i] = ((double*)ctx->pinned)[i];
+    MA_HIP(hipMemcpyAsync(scores_pinned_host, scores, nchunks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     *n_scores = (int)nchunks;
+    return MA_OK;
+}
+
+extern "C" {
+
+int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk, double* scores_host,
+              int max_scores, int* n_scores)
+{
+    MA_REQUIRE(ctx && scores_host && n_scores, "NULL argument");
+    const size_t nchunks = (chunk == 0 || chunk >= n || n == 0) ? 1 : (n + chunk - 1) / chunk;
+    MA_REQUIRE(nchunks <= 65535 && (size_t)max_scores >= nchunks, "scores buffer too small");
+    MA_TRY(ma_pinned_reserve(ctx, nchunks * sizeof(double)));
+    MA_TRY(ma_nmi_u8_enqueue(ctx, a, b, n, chunk, (double*)ctx->pinned, max_scores, n_scores));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < *n_scores; i++) scores_host[i] = ((double*)ctx->pinned)[i];
     return MA_OK;
 }
 

@@ -185,7 +185,7 @@ __device__ __forceinline__ int d_segment(int v, int T, int ov)
 // WARP_ROWS rows per thread: the flow loads of all rows are issued before the first gather, the gathers of all
 // rows before the first store -- 8 rows in flight per thread run 1.4x faster than one (measured, profiles/r01_notes.md)
 constexpr int WARP_ROWS = 8;
-constexpr int CELL_REPLICAS = 8;    // copies of the flow cell-maxima array (ma_warp_tiled_flowcells); 8 / 32 / 128 copies: warp 0.39 ms each, merge 0.26 / 0.29 / 0.36
+constexpr int CELL_REPLICAS = MA_FLOW_CELL_REPLICAS;    // the public header sizes the caller's buffer from the same constant; copies of the flow cell-maxima array (ma_warp_tiled_flowcells); 8 / 32 / 128 copies: warp 0.39 ms each, merge 0.26 / 0.29 / 0.36
 // MM: also reduce (min, max) of the block's output pixels into part[2 * block] (input conditioning of a following
 // dog(): the consumer then skips its own pass over the image)
 // cellkeys (may be NULL; needs T > 2*ov > 0): also fold the maximum of both FLOW components over the cells the window
@@ -574,6 +574,8 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
     dim3 grid((W + 255) / 256, (H + WARP_ROWS - 1) / WARP_ROWS), block(256);
     for (int i = 0; i < n_pages; i++) {
         Slot& s = slots[i % ns];  // stream order keeps the slot's buffers safe: copy-in waits for the previous copy-out
+        ctx->h2d_bytes += nb;
+        ctx->d2h_bytes += nb;
         PG_HIP(hipMemcpyAsync(s.din, pages_host[i], nb, hipMemcpyHostToDevice, s.st));
         if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t, false>), grid, block, 0, s.st, (const uint8_t*)s.din, g, f, (uint8_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0, 0);
         else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t, false>), grid, block, 0, s.st, (const uint16_t*)s.din, g, f, (uint16_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0, 0);

@@ -171,6 +171,7 @@ class Context:
 
     def trim(self):
         """Return every pooled buffer (device and host) to the driver."""
+        self.lib.ma_ctx_trim(self.handle)   # the intermediates ma_optflow_register caches on the C side
         for free in self._pool.values():
             for p in free:
                 self.lib.ma_free(self.handle, p)
@@ -238,6 +239,12 @@ class Context:
     def sync(self):
         L.check(self.lib.ma_sync(self.handle))
 
+    def transfer_stats(self, reset=False):
+        """(h2d_bytes, d2h_bytes) moved by this context's explicit host <-> device copies so far."""
+        up, down = C.c_ulonglong(), C.c_ulonglong()
+        L.check(self.lib.ma_ctx_transfer_stats(self.handle, C.byref(up), C.byref(down), int(bool(reset))))
+        return up.value, down.value
+
     def close(self):
         if not self._closed:
             L.check(self.lib.ma_sync(self.handle))
@@ -304,6 +311,23 @@ class Context:
                                             int(iterations), float(poly_sigma),
                                             L.MA_FB_MULADD_FUSED if fused else 0, flow.ptr, r0.ptr, r1.ptr, m0.ptr)
         return flow, r0, r1, m0
+
+    def optflow_register(self, ref, mov, num_pyr_lvl=4, num_iterations=3, tile_size=1000, overlap=100,
+                         use_full_res_img=False, use_dog=False, fb_flags=0, dog_flags=0):
+        """OptFlowRegistrator.register() as one C call (ma_optflow_register): device images in, (flow DeviceArray,
+        [(factor, (h, w), mi_after, mi_before, accepted), ...]) out.  The flow is enqueued, not synchronised."""
+        if ref.shape != mov.shape or ref.dtype != mov.dtype or ref.ndim != 2:
+            raise ValueError("ref/mov must be 2-D images of equal shape and dtype")
+        H, W = ref.shape
+        prm = L.MaParams(int(num_pyr_lvl), int(num_iterations), int(tile_size), int(overlap), int(bool(use_full_res_img)),
+                         int(bool(use_dog)), int(fb_flags), int(dog_flags))
+        nrep_max = max(int(num_pyr_lvl), 0) + 1
+        reps = (L.MaLevelReport * nrep_max)()
+        n = C.c_int(0)
+        flow = self.empty((H, W, 2), np.float32)
+        self._run(self.lib.ma_optflow_register, ref.ptr, mov.ptr, _dt(ref.dtype), H, W, C.byref(prm), flow.ptr, reps,
+                  nrep_max, C.byref(n))
+        return flow, [(r.factor, (r.h, r.w), r.mi_after, r.mi_before, bool(r.accepted)) for r in reps[:n.value]]
 
     def remap(self, src, map_xy):
         """cv2.remap(src, map_xy, None, INTER_LINEAR)."""

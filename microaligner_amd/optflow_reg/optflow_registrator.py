@@ -58,6 +58,9 @@ class OptFlowRegistrator:
         # dog() chain (GaussianBlur, normalize) with fused multiply-adds: what OpenCV's AVX2 + FMA3 objects compute
         # (MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE); default: the SSE2 baseline arithmetic
         self.dog_muladd_fused = False
+        # "c": the level loop runs inside the library (ma_optflow_register, one C call); "python": the same loop stated
+        # here over the primitive entry points (the second implementation the tests compare the first with)
+        self.engine = "c"
         self.level_reports: List[LevelReport] = []
         self._warper = Warper()
         self._tile_flow_calc = TileFlowCalc()
@@ -121,6 +124,21 @@ class OptFlowRegistrator:
 
         ref_full, mov_full = ctx.asdevice(self._ref_img), ctx.asdevice(self._mov_img)
         self._full_shape = ref_full.shape
+        if self.engine == "c":
+            if ref_full.dtype != mov_full.dtype:
+                raise ValueError(f"ref/mov dtypes differ: {ref_full.dtype} vs {mov_full.dtype}")
+            result, reports = ctx.optflow_register(
+                ref_full, mov_full, self.num_pyr_lvl, self.num_iterations, self.tile_size, self.overlap,
+                self.use_full_res_img, self.use_dog, L.MA_FB_MULADD_FUSED if self.muladd_fused else 0, self._dog_flags())
+            for factor, shape, after, before, accepted in reports:
+                self._log("Pyramid factor", factor)
+                self._log("    MI score after:", after, "| MI score before:", before)
+                self._log("    Better alignment than before" if accepted else "    Worse alignment than before")
+                self.level_reports.append(LevelReport(factor, tuple(shape), float(after), float(before), accepted))
+            self._ctx = None
+            return result if device_in else result.numpy()
+        if self.engine != "python":
+            raise ValueError(f"unknown engine {self.engine!r}: 'c' or 'python'")
         ref_pyr, factors = self._generate_img_pyr(ref_full)
         mov_pyr, _ = self._generate_img_pyr(mov_full)
 

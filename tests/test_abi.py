@@ -29,6 +29,59 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.ma_version()
 
 
+def test_constants_of_the_header_match_the_bindings():
+    """Enumerators and #defines that size caller-provided buffers or select rounding models exist three times (header,
+    kernels via the header, ctypes binding): the binding must carry the header's values."""
+    from microaligner_amd import _lib
+    text = open(HEADER).read()
+    vals = {k: int(v) for k, v in re.findall(r"\b(MA_[A-Z0-9_]+)\s*=\s*(-?\d+)", text)}
+    vals.update({k: int(v) for k, v in re.findall(r"#define\s+(MA_[A-Z0-9_]+)\s+(\d+)", text)})
+    for name in ("MA_U8", "MA_U16", "MA_F32", "MA_OK", "MA_EINVAL", "MA_ENOMEM", "MA_EHIP", "MA_ENODEV", "MA_FB_MULADD_FUSED",
+                 "MA_DOG_FUSED_BLUR", "MA_DOG_FUSED_SCALE", "MA_FLOW_CELL_REPLICAS"):
+        assert getattr(_lib, name) == vals[name], name
+    for name, kid in _lib.KERNEL_IDS.items():
+        assert vals["MA_K_" + name.upper()] == kid
+    # struct layouts: field names and order of ma_params / ma_level_report
+    for cname, cls in (("ma_params", _lib.MaParams), ("ma_level_report", _lib.MaLevelReport)):
+        body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", text, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                ctype, names = decl.split(None, 1)
+                fields += [(n.strip(), ctype) for n in names.split(",")]
+        assert [f[0] for f in cls._fields_] == [f[0] for f in fields], cname
+        for (_, ct), (_, decl_t) in zip(cls._fields_, fields):
+            assert {"int": C.c_int, "double": C.c_double}[decl_t] is ct
+
+
+def test_numpy_mean_replica_is_bit_identical():
+    """mi_tiled takes np.mean of the chunk scores (similarity_scoring.py:49); ma_optflow_register restates numpy's pairwise
+    summation on the host so that the gate compares the very same doubles."""
+    from microaligner_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 40)) + [63, 64, 65, 127, 128, 129, 130, 136, 137, 255, 256, 257, 269, 1000, 4097, 70000]:
+        for scale in (1.0, 1e-3, 1e3):
+            v = rng.random(n) * scale
+            out = C.c_double()
+            _lib.check(lib.ma_host_np_mean(v.ctypes.data_as(C.POINTER(C.c_double)), n, C.byref(out)))
+            assert out.value == np.mean(v), n
+    assert lib.ma_host_np_mean(None, 3, None) == _lib.MA_EINVAL
+
+
+def test_register_entry_rejects_bad_parameters_without_a_device():
+    from microaligner_amd import _lib
+    lib = _lib.load()
+    prm = _lib.MaParams()
+    lib.ma_params_default(C.byref(prm))
+    assert (prm.num_pyr_lvl, prm.num_iterations, prm.tile_size, prm.overlap, prm.use_full_res_img, prm.use_dog,
+            prm.fb_flags, prm.dog_flags) == (4, 3, 1000, 100, 0, 0, 0, 0)          # optflow_registrator.py:54-59
+    n = C.c_int()
+    assert lib.ma_optflow_register(None, None, None, 2, 10, 10, C.byref(prm), None, None, 0, C.byref(n)) == _lib.MA_EINVAL
+
+
 def test_code_object_targets_gfx950_only():
     from microaligner_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()

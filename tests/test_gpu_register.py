@@ -92,6 +92,51 @@ def test_register_in_the_fused_rounding_models_matches_the_oracle(dog_fused, fb_
     assert np.array_equal(reg.dog(ref, True), O.dog(ref, True, flags=O.DOG_FUSED if dog_fused else 0))
 
 
+@pytest.mark.parametrize("unrelated,dtype,params", [
+    (False, np.float32, dict(num_pyr_lvl=3, use_full_res_img=True, use_dog=True, tile_size=150, overlap=30)),
+    (False, np.uint8, dict(num_pyr_lvl=2, use_full_res_img=False, tile_size=200, overlap=40)),
+    (True, np.float32, dict(num_pyr_lvl=3, use_full_res_img=True, tile_size=150, overlap=30)),      # rejected levels
+    (True, np.uint16, dict(num_pyr_lvl=2, use_full_res_img=False, use_dog=True, tile_size=120, overlap=25)),
+    (False, np.float32, dict(num_pyr_lvl=0, use_full_res_img=True, tile_size=300, overlap=50)),     # a single level, in place
+    (True, np.float32, dict(num_pyr_lvl=0, use_full_res_img=True, tile_size=300, overlap=50)),
+    (False, np.float32, dict(num_pyr_lvl=1, use_full_res_img=False, tile_size=1000, overlap=100)),  # untiled, one pyrUp
+])
+def test_c_level_loop_equals_the_python_level_loop(unrelated, dtype, params):
+    """ma_optflow_register (the level loop, gate and bookkeeping in C++ behind one entry point) against the same loop
+    stated in Python over the primitive entry points: flows, per-level decisions and MI scores identical, on accepted
+    and rejected levels, every dtype, with and without the full-resolution level."""
+    make = synthetic.make_unrelated_pair if unrelated else synthetic.make_pair
+    ref, mov = make(840, 700, 17, dtype)
+    out = {}
+    for engine in ("c", "python"):
+        reg = make_reg(dict(params, engine=engine))
+        reg.ref_img, reg.mov_img = ref, mov
+        out[engine] = (reg.register(), [(r.factor, r.shape, r.mi_after, r.mi_before, r.accepted) for r in reg.level_reports])
+    assert out["c"][1] == out["python"][1]
+    assert out["c"][0].shape == ref.shape + (2,) and np.array_equal(out["c"][0], out["python"][0])
+    exp, reports = RO.register(ref, mov, **params)
+    assert np.array_equal(out["c"][0], exp) and [r[4] for r in out["c"][1]] == [r[3] for r in reports]
+
+
+def test_c_register_errors():
+    reg = make_reg(dict(num_pyr_lvl=3))
+    reg.ref_img = reg.mov_img = np.ones((150, 150), np.float32)      # no level keeps 100 px
+    with pytest.raises(ValueError, match="too small"):
+        reg.register()
+    reg = make_reg(dict(num_pyr_lvl=0, use_full_res_img=False))
+    reg.ref_img = reg.mov_img = np.ones((300, 300), np.float32)
+    with pytest.raises(ValueError, match="use_full_res_img is False"):
+        reg.register()
+    reg = make_reg(dict(num_pyr_lvl=-1))
+    reg.ref_img = reg.mov_img = np.ones((300, 300), np.float32)
+    with pytest.raises(ValueError, match="cannot be less than 0"):
+        reg.register()
+    reg = make_reg(dict(engine="fortran"))
+    reg.ref_img = reg.mov_img = np.ones((300, 300), np.float32)
+    with pytest.raises(ValueError, match="unknown engine"):
+        reg.register()
+
+
 def test_device_resident_inputs_stay_on_device(ctx):
     ref, mov = synthetic.make_pair(420, 404, 1)
     reg = make_reg(dict(num_pyr_lvl=2, use_full_res_img=True, tile_size=100, overlap=20))
