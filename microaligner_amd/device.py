@@ -4,9 +4,12 @@ Thin Python over the C-ABI (include/microaligner_hip.h).  One `Context` per HIP
 device per process; `DeviceArray` is a dense row-major array in HBM.  All work is
 stream ordered on the context's stream, so intermediate results never visit the host.
 """
+import collections
 import ctypes as C
 import os
 import threading
+import weakref
+import zlib
 
 import numpy as np
 
@@ -65,6 +68,9 @@ class DeviceArray:
             raise ValueError(f"out must be a writable C-contiguous {self.dtype} array of shape {self.shape}")
         if out.nbytes:
             L.check(self.ctx.lib.ma_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
+        self.ctx._resident.remember(out, self)   # asdevice(out) will find this array instead of uploading it again
+        if self.ctx._resident.mode == "readonly" and self.ctx._resident._eligible(out):
+            out.flags.writeable = False          # the hard form of the write guard: results cannot be edited in place
         return out
 
     def _check_alive(self):
@@ -92,7 +98,7 @@ class _HostBuffer:
     """Owner of one page-locked host buffer; exposes it through __array_interface__ so that numpy arrays built on
     it keep it alive (base chain), and hands the memory back to the pool when it dies."""
 
-    __slots__ = ("ctx", "ptr", "bucket", "nbytes")
+    __slots__ = ("ctx", "ptr", "bucket", "nbytes", "__weakref__")   # weakly referenced by the resident-pair cache
 
     def __init__(self, ctx, ptr, bucket, nbytes):
         self.ctx, self.ptr, self.bucket, self.nbytes = ctx, ptr, bucket, nbytes
@@ -108,6 +114,102 @@ class _HostBuffer:
             pass
 
 
+class _ResidentCache:
+    """Host array <-> device array pairs that are known to hold the same bytes.
+
+    The reference's callers move every array through numpy: register() returns the flow, the very next statement
+    hands it to Warper (microaligner/__main__.py:418-433), and warp_and_save_pages sets the same flow on the warper
+    for every page of a cycle (:296-301).  Through a drop-in API that is one 2.1 GB upload per call at 16384^2.  This
+    cache lets Context.asdevice() recognise a host array it has uploaded or downloaded before and return the device
+    array that is still alive instead:
+
+      * key: address, shape, strides and dtype of the host array (C-contiguous arrays of at least MIN_BYTES only);
+      * liveness: a weak reference to the object that owns the memory (the end of the array's .base chain); when it
+        dies the entry goes with it, so a recycled address can never match;
+      * write guard: a CRC of head, tail and SAMPLES evenly strided bytes of the array, taken when the pair is
+        recorded and checked on every hit.  Whole-array and block updates change it; an edit of a few isolated
+        elements can escape it.  MICROALIGNER_RESIDENT=readonly hands results out read-only instead (a hard guarantee:
+        writes raise), MICROALIGNER_RESIDENT=off disables the cache;
+      * bound: least recently used pairs are dropped beyond MICROALIGNER_RESIDENT_GB (default 16) of device memory.
+
+    Device arrays are never modified in place (every operation allocates its output), so a recorded pair stays valid
+    for as long as the host side is untouched."""
+
+    MIN_BYTES = 1 << 20
+    SAMPLES = 8192
+    EDGE = 4096
+
+    def __init__(self):
+        self.mode = os.environ.get("MICROALIGNER_RESIDENT", "sampled").lower()
+        if self.mode not in ("sampled", "readonly", "off"):
+            raise ValueError("MICROALIGNER_RESIDENT must be one of sampled, readonly, off")
+        self.limit = int(float(os.environ.get("MICROALIGNER_RESIDENT_GB", "16")) * (1 << 30))
+        self.entries = collections.OrderedDict()   # key -> [weakref(owner), DeviceArray, signature]
+        self.bytes = 0
+        self.hits = 0
+
+    @staticmethod
+    def _key(arr):
+        return (arr.__array_interface__["data"][0], arr.shape, arr.strides, arr.dtype.str)
+
+    @staticmethod
+    def _owner(arr):
+        while isinstance(getattr(arr, "base", None), np.ndarray):
+            arr = arr.base
+        return arr.base if getattr(arr, "base", None) is not None else arr
+
+    @classmethod
+    def _signature(cls, arr):
+        b = arr.reshape(-1).view(np.uint8)
+        n = b.size
+        step = max(1, n // cls.SAMPLES) | 1
+        crc = zlib.crc32(b[:cls.EDGE].tobytes())
+        crc = zlib.crc32(b[-cls.EDGE:].tobytes(), crc)
+        return zlib.crc32(b[::step].tobytes(), crc)
+
+    def _eligible(self, arr):
+        return (self.mode != "off" and isinstance(arr, np.ndarray) and arr.flags.c_contiguous
+                and arr.nbytes >= self.MIN_BYTES)
+
+    def remember(self, arr, dev):
+        if not self._eligible(arr) or dev.ptr is None:
+            return
+        key = self._key(arr)
+        try:
+            ref = weakref.ref(self._owner(arr), lambda _r, k=key: self._forget(k))
+        except TypeError:       # the memory owner cannot be weakly referenced (mmap, bytes): liveness unknown
+            return
+        self._forget(key)
+        self.entries[key] = [ref, dev, self._signature(arr)]
+        self.bytes += dev.nbytes
+        while self.bytes > self.limit and len(self.entries) > 1:
+            self._forget(next(iter(self.entries)))
+
+    def _forget(self, key):
+        e = self.entries.pop(key, None)
+        if e is not None:
+            self.bytes -= e[1].nbytes if e[1].ptr is not None else 0
+
+    def lookup(self, arr):
+        if not self._eligible(arr):
+            return None
+        key = self._key(arr)
+        e = self.entries.get(key)
+        if e is None:
+            return None
+        ref, dev, sig = e
+        if ref() is None or dev.ptr is None or dev.shape != arr.shape or dev.dtype != arr.dtype or self._signature(arr) != sig:
+            self._forget(key)
+            return None
+        self.entries.move_to_end(key)
+        self.hits += 1
+        return dev
+
+    def clear(self):
+        self.entries.clear()
+        self.bytes = 0
+
+
 class Context:
     """One per HIP device.  Owns the C-side ma_ctx and a size-bucketed pool of HBM buffers."""
 
@@ -121,7 +223,9 @@ class Context:
         self._live = {}        # ptr -> bucket of every buffer handed out and not yet released
         self._host_pool = {}   # bucket -> [pinned host pointers] (result arrays of the numpy-in / numpy-out API)
         self._host_owned = {}  # bucket -> page-locked buffers this context owns (handed out + pooled)
-        self._host_lock = threading.Lock()
+        self._host_lock = threading.RLock()   # re-entrant: a pinned result array finalised by a GC pass that starts inside
+        #                                        _host_release() comes back here on the same thread
+        self._resident = _ResidentCache()
         self._closed = False
         lim = os.environ.get("MICROALIGNER_WORKSPACE_GB")
         if lim:
@@ -133,10 +237,10 @@ class Context:
         dtype = np.dtype(dtype)
         nbytes = max(int(np.prod(shape, dtype=np.int64)) * dtype.itemsize, 1)
         bucket = (nbytes + 0xFFFF) & ~0xFFFF
-        free = self._pool.get(bucket)
-        if free:
-            ptr = free.pop()
-        else:
+        with self._host_lock:    # _release() runs from __del__, i.e. from whichever thread the collector picks
+            free = self._pool.get(bucket)
+            ptr = free.pop() if free else None
+        if ptr is None:
             p = C.c_void_p()
             rc = self.lib.ma_malloc(self.handle, bucket, C.byref(p))
             if rc == L.MA_ENOMEM:
@@ -144,7 +248,8 @@ class Context:
                 rc = self.lib.ma_malloc(self.handle, bucket, C.byref(p))
             L.check(rc)
             ptr = p.value
-        self._live[ptr] = bucket
+        with self._host_lock:
+            self._live[ptr] = bucket
         return DeviceArray(self, shape, dtype, ptr, bucket)
 
     def zeros(self, shape, dtype):
@@ -153,29 +258,38 @@ class Context:
         return a
 
     def asdevice(self, arr):
-        """numpy -> DeviceArray (H2D copy); DeviceArray passes through."""
+        """numpy -> DeviceArray (H2D copy); DeviceArray passes through.  A host array this context has uploaded or
+        downloaded before, whose memory is still alive and unmodified (_ResidentCache), maps to the device array that
+        already holds it: no copy."""
         if isinstance(arr, DeviceArray):
             return arr
         arr = np.ascontiguousarray(arr)
         _dt(arr.dtype)
+        d = self._resident.lookup(arr)
+        if d is not None:
+            return d
         d = self.empty(arr.shape, arr.dtype)
         if arr.nbytes:
             L.check(self.lib.ma_memcpy_h2d(self.handle, d.ptr, arr.ctypes.data, arr.nbytes))
+        self._resident.remember(arr, d)
         return d
 
     def _release(self, ptr, bucket):
-        if self._closed:
-            return   # close() already returned every outstanding buffer to the driver
-        self._live.pop(ptr, None)
-        self._pool.setdefault(bucket, []).append(ptr)
+        with self._host_lock:
+            if self._closed:
+                return   # close() already returned every outstanding buffer to the driver
+            self._live.pop(ptr, None)
+            self._pool.setdefault(bucket, []).append(ptr)
 
     def trim(self):
         """Return every pooled buffer (device and host) to the driver."""
+        self._resident.clear()
         self.lib.ma_ctx_trim(self.handle)   # the intermediates ma_optflow_register caches on the C side
-        for free in self._pool.values():
+        with self._host_lock:
+            dev_pool, self._pool = self._pool, {}
+        for free in dev_pool.values():
             for p in free:
                 self.lib.ma_free(self.handle, p)
-        self._pool = {}
         with self._host_lock:
             pools, self._host_pool = self._host_pool, {}
             for bucket, free in pools.items():
@@ -239,6 +353,11 @@ class Context:
     def sync(self):
         L.check(self.lib.ma_sync(self.handle))
 
+    def forget_host_arrays(self):
+        """Drop every recorded host <-> device pair (Context.asdevice() uploads afresh); device memory held only by the
+        pairs goes back to the pool."""
+        self._resident.clear()
+
     def transfer_stats(self, reset=False):
         """(h2d_bytes, d2h_bytes) moved by this context's explicit host <-> device copies so far."""
         up, down = C.c_ulonglong(), C.c_ulonglong()
@@ -250,10 +369,11 @@ class Context:
             L.check(self.lib.ma_sync(self.handle))
             self.trim()
             # arrays that outlive the context: their HBM goes back to the driver now (they raise if used again)
-            for p in list(self._live):
+            with self._host_lock:
+                live, self._live = list(self._live), {}
+                self._closed = True
+            for p in live:
                 self.lib.ma_free(self.handle, p)
-            self._live = {}
-            self._closed = True
             self.lib.ma_ctx_destroy(self.handle)
 
     def __del__(self):

@@ -298,6 +298,78 @@ def test_page_warp_driver_matches_single_page_warps(ctx):
         w.warp_pages([pages[0][:10]])
 
 
+def test_reference_shaped_numpy_loop_uploads_nothing_twice(ctx):
+    """The reference's own statements, numpy in and numpy out (microaligner/__main__.py:418-433 and the per-page loop
+    of warp_and_save_pages :296-301): register(), then Warper.warp() of the moving image, then the same flow set on the
+    warper for each of 8 uint16 pages.  Results equal the oracle; the context's transfer counters show that the flow is
+    never uploaded (register() produced it, the host copy it returned is recognised) and the moving image only once."""
+    params = dict(num_pyr_lvl=2, use_full_res_img=True, tile_size=200, overlap=40)
+    H, W = 700, 620
+    ref, mov = synthetic.make_pair(H, W, seed=9)
+    rng = np.random.default_rng(2)
+    pages = [rng.integers(0, 65535, (H, W)).astype(np.uint16) for _ in range(8)]
+    ctx.trim()
+    ctx.sync()
+    ctx.transfer_stats(reset=True)
+    reg = make_reg(params)
+    reg.ref_img, reg.mov_img = ref, mov
+    flow = reg.register()
+    assert isinstance(flow, np.ndarray) and flow.flags.writeable
+    w = Warper()
+    w.tile_size, w.overlap = 200, 40
+    w.image, w.flow = mov, flow                     # __main__.py:421-424
+    warped = w.warp()
+    out = []
+    for page in pages:                              # __main__.py:296-301
+        w.image = page
+        w.flow = flow
+        out.append(w.warp())
+    up, down = ctx.transfer_stats()
+    page_bytes = sum(p.nbytes for p in pages)
+    assert up == ref.nbytes + mov.nbytes + page_bytes, f"uploaded {up} bytes"
+    assert down == flow.nbytes + warped.nbytes + page_bytes
+    exp_flow, _ = RO.register(ref, mov, **params)
+    assert np.array_equal(flow, exp_flow) and np.array_equal(warped, RO.warp(mov, exp_flow, 200, 40))
+    for p, o in zip(pages, out):
+        assert o.dtype == np.uint16 and np.array_equal(o, RO.warp(p, exp_flow, 200, 40))
+    # an edited flow is noticed (the sampled write guard) and uploaded again; so is a new array at a recycled address
+    flow *= 0.5
+    ctx.transfer_stats(reset=True)
+    w.image, w.flow = pages[0], flow
+    again = w.warp()
+    assert ctx.transfer_stats()[0] == flow.nbytes + pages[0].nbytes
+    assert np.array_equal(again, RO.warp(pages[0], flow, 200, 40))
+    n_before = len(ctx._resident.entries)
+    del flow, exp_flow, w
+    import gc
+    gc.collect()
+    assert len(ctx._resident.entries) < n_before      # the pair dies with the host array
+
+
+def test_resident_cache_modes(monkeypatch):
+    """MICROALIGNER_RESIDENT=readonly hands results out read-only (the hard write guard); =off uploads every time."""
+    from microaligner_amd.device import Context, use_context
+    img, _ = synthetic.make_pair(600, 600, seed=3)
+    flow = np.full((600, 600, 2), 1.5, np.float32)
+    for mode, uploads in (("readonly", 1), ("off", 2), ("sampled", 1)):
+        monkeypatch.setenv("MICROALIGNER_RESIDENT", mode)
+        c = Context(0)
+        try:
+            with use_context(c):
+                w = Warper()
+                for _ in range(2):
+                    w.image, w.flow = img, flow
+                    res = w.warp()
+                assert c.transfer_stats()[0] == uploads * (img.nbytes + flow.nbytes)
+                assert res.flags.writeable == (mode != "readonly")
+                assert np.array_equal(res, RO.warp(img, flow, 1000, 100))
+        finally:
+            c.close()
+    monkeypatch.setenv("MICROALIGNER_RESIDENT", "sometimes")
+    with pytest.raises(ValueError):
+        Context(0)
+
+
 def test_register_pairs_with_lanes_matches_single_lane():
     """Several pairs in flight on one GPU (one context and host thread per lane) give the same bits."""
     from microaligner_amd import parallel

@@ -122,3 +122,42 @@ def test_lanes_run_every_unit_once_under_their_own_context(monkeypatch):
 
     with pytest.raises(RuntimeError, match="boom"):
         parallel.run_sharded(list(range(8)), bad, lanes=2)
+
+
+def test_resident_cache_recognises_unmodified_host_arrays_only():
+    """The host <-> device pair cache behind Context.asdevice() (no device needed: a stand-in device array): same memory
+    and same bytes hit, edits and recycled or dead memory miss, small arrays are never recorded, the byte bound evicts
+    the least recently used pair."""
+    import gc
+    import numpy as np
+    from microaligner_amd.device import _ResidentCache
+
+    class Dev:
+        def __init__(self, a):
+            self.ptr, self.shape, self.dtype, self.nbytes = 1, a.shape, a.dtype, a.nbytes
+
+    c = _ResidentCache()
+    a = np.random.default_rng(0).random((600, 600)).astype(np.float32)
+    d = Dev(a)
+    c.remember(a, d)
+    assert c.lookup(a) is d and c.lookup(a[:]) is d and c.hits == 2      # a view of the same memory is the same array
+    assert c.lookup(a[:300]) is None and c.lookup(a.copy()) is None
+    a *= 2
+    assert c.lookup(a) is None and not c.entries                          # edited: forgotten, will be uploaded again
+    b = np.ones((600, 600), np.float32)
+    c.remember(b, Dev(b))
+    assert len(c.entries) == 1
+    del b
+    gc.collect()
+    assert not c.entries and c.bytes == 0                                 # the pair dies with the host memory
+    small = np.zeros(10, np.float32)
+    c.remember(small, Dev(small))
+    assert not c.entries
+    c.limit = 3 * a.nbytes
+    keep = [np.full((600, 600), i, np.float32) for i in range(5)]
+    for k in keep:
+        c.remember(k, Dev(k))
+    assert len(c.entries) == 3 and c.lookup(keep[0]) is None and c.lookup(keep[4]) is not None
+    d.ptr = None
+    c.remember(a, d)
+    assert c.lookup(a) is None                                            # a freed device array is never handed out
