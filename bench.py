@@ -28,7 +28,14 @@ sys.path.insert(0, ROOT)
 
 METRIC = "Mpix/s optical-flow reg+warp, 16k×16k float32 tile, 1/2/4/8 GPU"  # BASELINE.json
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-VALU_PK_PEAK_TLOPS = 71.4  # packed FP32 lane-ops/s measured with v_pk_mul_f32 at 8 waves/SIMD (profiles/r01_ubench_valu.txt)
+NOMINAL_GHZ = 2.4      # MI355X_MICROARCH.md, chip-level parameters
+# FP32 vector peak for the NON-fused arithmetic of the window blurs and the DOG (one flop per lane and instruction
+# slot: v_pk_add / v_pk_mul): 256 CUs x 4 SIMDs x 32 lanes per clock = 78.6 TFLOP/s at 2.4 GHz -- half of the 157.3
+# TFLOP/s the data sheet quotes for fused multiply-adds.  The chip does not hold 2.4 GHz in these kernels (it is power
+# limited: profiles/r03_notes.md); ma_clock_probe measures the clock it sustains under the same instruction mix in the
+# same run, and `frac` is taken against the peak at THAT clock, the nominal one is reported beside it.
+VALU_LANES_PER_CLOCK = 256 * 4 * 32
+VALU_BOUND = ("blur_v", "blur_h_solve", "dog")
 
 CFG2 = dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=False)
 WORKLOADS = {
@@ -77,42 +84,69 @@ def pmc_traffic(workload):
     """HBM bytes per step and kernel group from the newest committed rocprofv3 PMC summary of this very command
     (profiles/rNN_hbm_traffic_<workload>.json, tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE
     passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the bench,
-    so the JSON line names the file the bytes come from (`traffic_source`); it is regenerated whenever a kernel's
-    I/O changes."""
+    so the JSON line names the file the bytes come from (`traffic_source`).  A summary is only quoted when it was
+    collected with the very kernels that are loaded now: it records the hash of the kernel sources (ma_version()),
+    and a summary with another hash -- or none -- yields `traffic: null` and says why."""
     import glob
+    from microaligner_amd import _lib
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_hbm_traffic_{workload}.json")))
     if not files:
-        return {}, None
-    return json.load(open(files[-1])).get("per_bench_group_bytes_per_step", {}), os.path.relpath(files[-1], ROOT)
+        return {}, None, "no PMC summary committed for this workload"
+    rel = os.path.relpath(files[-1], ROOT)
+    summary = json.load(open(files[-1]))
+    have, want = summary.get("kernel_source_hash"), _lib.source_hash()
+    if have != want:
+        return {}, None, f"{rel} was collected with kernel sources {have}, the loaded library is {want}"
+    return summary.get("per_bench_group_bytes_per_step", {}), rel, None
 
 
-def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsize_taps=0, traffic_source=None):
+def valu_flops_per_px(kernel, winsize_taps, fused):
+    """FP32 lane-operations per processed pixel of the VALU-bound kernels (what a perfect schedule must still issue).
+    Window blurs: 5 planes x (k0 * c, then per tap pair add, multiply, add -- or add, fma).  DOG: two sigmas x (row
+    filter of 41 taps: 41 multiplies + 40 additions; column filter: 1 multiply + 20 x (add, multiply, add)) + the
+    difference + the two normalisations (multiply, add)."""
+    if kernel in ("blur_v", "blur_h_solve"):
+        return 5 * ((2 if fused else 3) * winsize_taps + 1)
+    if kernel == "dog":
+        return 2 * ((41 + 40) + (1 + 20 * 3)) + 1 + 4
+    return 0
+
+
+def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsize_taps=0, traffic_source=None,
+                   clock_ghz=None, fused=False, traffic_note=None):
     if rec["launches"] == 0 or rec["ms"] <= 0:
         return None
     bpp = algorithmic_bytes_per_px(name, iters, esz)
-    gbs = bpp * rec["px"] / (rec["ms"] * 1e-3) / 1e9
+    sec = rec["ms"] * 1e-3
+    gbs = bpp * rec["px"] / sec / 1e9
     traffic = None
     if traffic_per_step and name in traffic_per_step:
         traffic = round(traffic_per_step[name] * steps / rec["launches"])  # HBM bytes per launch (PMC)
-    out = {"kernel": name, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": traffic,
+    hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    out = {"kernel": name, "bound": "hbm", **hbm, "traffic": traffic,
            "traffic_source": traffic_source if traffic is not None else None,
            "avg_launch_ms": round(rec["ms"] / rec["launches"], 4), "launches": rec["launches"],
            "algorithmic_bytes_per_launch": round(bpp * rec["px"] / rec["launches"]),
            "algorithmic_bytes_per_px": round(bpp, 2), "px_per_launch": round(rec["px"] / rec["launches"])}
+    if traffic is None and traffic_note:
+        out["traffic_note"] = traffic_note
     if traffic is not None and traffic < 0.8 * out["algorithmic_bytes_per_launch"]:
         # fewer HBM bytes than algorithmic bytes: the producer's output is still in L2 / the 256 MB infinity cache and
         # write-backs complete after the kernel; `achieved` (algorithmic bytes per second) can then exceed the HBM peak
         out["note"] = ("PMC traffic below the algorithmic bytes: part of this kernel's data is served by L2 / infinity "
                        "cache; `achieved` is not pure HBM bandwidth")
-    if name in ("blur_v", "blur_h_solve") and winsize_taps:
-        # informational: these two kernels are bound by packed-FP32 issue, not by HBM.  FIR work = 5 planes x
-        # (3 lane-ops per tap pair + 1) per pixel; peak = the v_pk_mul_f32 rate measured on this GPU
-        # (profiles/r01_ubench_valu.txt, 8 waves/SIMD)
-        lane_ops = 5 * (3 * winsize_taps + 1) * rec["px"]
-        tl = lane_ops / (rec["ms"] * 1e-3) / 1e12
-        out["valu"] = {"achieved": round(tl, 2), "peak": VALU_PK_PEAK_TLOPS, "unit": "T lane-ops/s (fp32, unfused)",
-                       "frac": round(tl / VALU_PK_PEAK_TLOPS, 4)}
+    if name in VALU_BOUND and (winsize_taps or name == "dog"):
+        # these kernels are bound by FP32 vector issue, not by HBM: price them against the VALU peak at the clock the
+        # chip sustains under this instruction mix (ma_clock_probe, same run); the HBM view stays in `hbm`
+        fpp = valu_flops_per_px(name, winsize_taps, fused)
+        tf = fpp * rec["px"] / sec / 1e12
+        ghz = clock_ghz or NOMINAL_GHZ
+        peak = VALU_LANES_PER_CLOCK * ghz * 1e9 / 1e12
+        out.update({"bound": "valu", "achieved": round(tf, 2), "peak": round(peak, 2), "unit": "TFLOP/s",
+                    "frac": round(tf / peak, 4), "peak_nominal": round(VALU_LANES_PER_CLOCK * NOMINAL_GHZ * 1e9 / 1e12, 2),
+                    "frac_of_nominal": round(tf / (VALU_LANES_PER_CLOCK * NOMINAL_GHZ * 1e9 / 1e12), 4),
+                    "clock_ghz": round(ghz, 3), "clock_source": "ma_clock_probe, same run" if clock_ghz else "nominal",
+                    "flops_per_px": fpp, "arithmetic": "fma" if fused else "mul+add (3 ops per tap pair)", "hbm": hbm})
     return out
 
 
@@ -251,7 +285,9 @@ def free_port():
 def launch_ranks(n, argv):
     """Start n rank processes of this script and forward rank 0's stdout.  Nothing in this process has touched HIP
     (no microaligner_amd import, no torch.cuda call) -- the ranks are plain children, never an exec of a process
-    that initialised the GPU."""
+    that initialised the GPU.  Rank 0's stdout is drained by a reader thread while the ranks run, so a chatty rank
+    can never fill the pipe and block."""
+    import threading
     port = free_port()
     procs = []
     for r in range(n):
@@ -260,6 +296,9 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
     pending = set(range(n))
     while pending:
@@ -275,17 +314,27 @@ def launch_ranks(n, argv):
                     procs[q].terminate()   # exact children of this process, by handle
         if pending:
             time.sleep(0.05)
-    out = procs[0].stdout.read().decode()
+    reader.join(timeout=30)
+    out = b"".join(chunks).decode()
     json_lines = [line for line in out.splitlines() if line.startswith("{")]
     for line in out.splitlines():      # anything else rank 0 wrote to stdout (library chatter) goes to stderr
         if not line.startswith("{"):
             print(line, file=sys.stderr)
     sys.stdout.write("".join(line + "\n" for line in json_lines))
     sys.stdout.flush()
-    if rc == 0 and not any(line.startswith("{") for line in out.splitlines()):
+    if rc == 0 and not json_lines:
         print("bench.py: rank 0 printed no JSON line", file=sys.stderr)
         rc = 1
     return rc
+
+
+def rank_table(dist, world, rank, row):
+    """Every rank's row (a small dict) on rank 0, in rank order: per-rank times, device identity, HBM state."""
+    if dist is None:
+        return [row]
+    rows = [None] * world
+    dist.all_gather_object(rows, row)
+    return rows
 
 
 def main():
@@ -297,13 +346,19 @@ def main():
     ap.add_argument("--size", type=int, default=0, help="override H=W of the workload")
     ap.add_argument("--dtype", default="f32", choices=["f32", "u8"], help="input dtype (u8: the pipeline-faithful cfg4 variant)")
     ap.add_argument("--fused", action="store_true", help="window blur with FMA (MA_FB_MULADD_FUSED)")
+    ap.add_argument("--dog-fused", action="store_true", help="dog() chain with FMA (MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dog", action="store_true", help="experiment: run the workload with use_dog=False")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational legs (profiling runs)")
-    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=0,
+                    help="edge of the CPU-baseline sample; 0: the full workload on hosts with >= 128 hardware threads "
+                         "(the 16384^2 oracle run takes ~45 s there), else 4096")
     ap.add_argument("--lanes", type=int, default=3, help="pairs in flight for the informational multi-lane leg (0: skip)")
     ap.add_argument("--feature-init", action="store_true",
                     help="cfg5: FeatureRegistrator.register() supplies the affine initialisation inside the timed step")
+    ap.add_argument("--pairs-total", type=int, default=0,
+                    help="a step is one pass over K independent pairs dealt round-robin to the ranks (BASELINE cfg4: 8 "
+                         "cycle pairs, cfg5: 64 mosaic tiles) instead of one pair per rank; scaling is then strong")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduce plumbing only, no GPU work (CPU test of the N-rank launcher)")
     args = ap.parse_args()
@@ -336,6 +391,9 @@ def main():
     params = dict(wl["params"])
     if args.no_dog:
         params["use_dog"] = False
+    # the pairs of this rank: its own pair (weak scaling), or its share of K pairs dealt round-robin (strong scaling)
+    my_pairs = list(range(rank, args.pairs_total, world)) if args.pairs_total else [rank]
+    pairs_per_step = args.pairs_total or world
 
     def reduce_max(x):
         if dist is None:
@@ -348,11 +406,17 @@ def main():
     if args.dry_run:
         if dist is not None:
             dist.barrier()
-        elapsed = reduce_max(1e-3 * args.steps)
+        mine = 1e-3 * args.steps * (1 + 0.01 * rank)
+        elapsed = reduce_max(mine)
+        rows = rank_table(dist, world, rank, {"rank": rank, "ms_per_step": mine / args.steps * 1e3, "pairs": my_pairs,
+                                               "device": None, "pci_bus_id": None})
         if rank == 0:
+            per = [r["ms_per_step"] for r in rows]
             print(json.dumps({"metric": METRIC, "value": None, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "dry_run": True,
-                              "config": {"workload": args.workload, "pairs_per_step": world}}))
+                              "config": {"workload": args.workload, "pairs_per_step": pairs_per_step},
+                              "ranks": rows,
+                              "rank_ms_per_step": {"min": min(per), "mean": sum(per) / len(per), "max": max(per)}}))
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -360,46 +424,56 @@ def main():
 
     import numpy as np
     from microaligner_amd import OptFlowRegistrator, Warper, synthetic
-    from microaligner_amd.device import device_count, get_context
+    from microaligner_amd.device import device_count, device_info, get_context
 
     ndev = device_count()
     if ndev < 1:
         raise RuntimeError("no HIP device: the benchmark has no CPU path")
     # one process per GPU; on a box with fewer GPUs than ranks (the 1-GPU test box) ranks share devices, which the
     # JSON line states (`devices`)
-    os.environ["MICROALIGNER_DEVICE"] = str(local_rank % ndev)   # what get_context() inside register()/warp() picks up
+    dev_index = local_rank % ndev
+    os.environ["MICROALIGNER_DEVICE"] = str(dev_index)   # what get_context() inside register()/warp() picks up
     ctx = get_context()
 
     np_dtype = np.uint8 if args.dtype == "u8" else np.float32
-    inv_affine, freg = None, None
-    if wl.get("affine"):
-        # mosaic tile: cell-like texture, the moving image misplaced by a known similarity (rotation <= 0.5 deg,
-        # shift <= 20 px) plus a smooth residual.  Affine initialisation: the known matrix (default; SURVEY 8d:
-        # "ground-truth matrix where opencv-contrib is absent") or, with --feature-init, FeatureRegistrator.register()
-        # inside the timed step (its sparse selection / matching glue runs on the host)
-        ref, mov, M = synthetic.make_mosaic_tile(H, W, seed=1 + rank, dtype=np_dtype)
-        inv_affine = np.vstack([M, [0, 0, 1]])        # pinv of the 3x3 of T = M^-1: what transform_img_with_tmat applies
-        if args.feature_init:
-            from microaligner_amd import FeatureRegistrator
-            freg = FeatureRegistrator()
-            freg.verbose = False
-    else:
-        ref, mov = synthetic.make_pair(H, W, seed=1 + rank, dtype=np_dtype)
-    dref, dmov = ctx.asdevice(ref), ctx.asdevice(mov)
-    if not (world == 1 and not args.no_variants) and freg is None:
-        del ref, mov
+    freg = None
+    if wl.get("affine") and args.feature_init:
+        from microaligner_amd import FeatureRegistrator
+        freg = FeatureRegistrator()
+        freg.verbose = False
+    # (ref, mov) device pairs of this rank; for the mosaic workload also the known inverse matrix and the host arrays
+    # FeatureRegistrator takes
+    work = []
+    for idx in my_pairs:
+        inv_affine, host = None, None
+        if wl.get("affine"):
+            # mosaic tile: cell-like texture, the moving image misplaced by a known similarity (rotation <= 0.5 deg,
+            # shift <= 20 px) plus a smooth residual.  Affine initialisation: the known matrix (default; SURVEY 8d:
+            # "ground-truth matrix where opencv-contrib is absent") or, with --feature-init, FeatureRegistrator.register()
+            # inside the timed step (its sparse selection / matching glue runs on the host)
+            ref, mov, M = synthetic.make_mosaic_tile(H, W, seed=1 + idx, dtype=np_dtype)
+            inv_affine = np.vstack([M, [0, 0, 1]])    # pinv of the 3x3 of T = M^-1: what transform_img_with_tmat applies
+            host = (ref, mov) if freg is not None else None
+        else:
+            ref, mov = synthetic.make_pair(H, W, seed=1 + idx, dtype=np_dtype)
+        work.append((ctx.asdevice(ref), ctx.asdevice(mov), inv_affine, host))
+    keep_host = world == 1 and not args.no_variants and not args.pairs_total
+    if not keep_host and freg is None:
+        ref = mov = None
+    ctx.forget_host_arrays()
 
     reg = OptFlowRegistrator()
     reg.verbose = False
     reg.muladd_fused = args.fused
+    reg.dog_muladd_fused = args.dog_fused
     for k, v in params.items():
         setattr(reg, k, v)
     warper = Warper()
     warper.tile_size, warper.overlap = reg.tile_size, reg.overlap
 
-    def step():
+    def one_pair(dref, dmov, inv_affine, host):
         if freg is not None:
-            freg.ref_img, freg.mov_img = ref, mov
+            freg.ref_img, freg.mov_img = host
             t_mat = freg.register()
             m = ctx.warp_affine(dmov, np.linalg.pinv(np.vstack([t_mat, [0, 0, 1]])))
         else:
@@ -407,7 +481,13 @@ def main():
         reg.ref_img, reg.mov_img = dref, m
         flow = reg.register()
         warper.image, warper.flow = m, flow
-        return warper.warp()
+        return flow, warper.warp()
+
+    def step():
+        out = None
+        for item in work:
+            out = one_pair(*item)
+        return out
 
     def barrier():
         ctx.sync()
@@ -427,6 +507,23 @@ def main():
     barrier()
     ctx.profile(False)
     elapsed = reduce_max(t1 - t0)
+    # the shader clock the chip holds under the blur kernels' instruction mix, while it is still hot
+    clock_ghz = ctx.clock_probe(20.0)
+    # results of the sharded job come back to rank 0 over gloo (host side), timed apart from the device time: per pair a
+    # checksum of the flow and of the warped image (the arrays themselves stay where the next pipeline stage needs them)
+    tg0 = time.perf_counter()
+    summary = None
+    if out is not None:
+        flow, warped = out
+        summary = {"pair": my_pairs[-1] if my_pairs else None, "flow_minmax": [float(v) for v in ctx.minmax(flow)],
+                   "warped_minmax": [float(v) for v in ctx.minmax(warped)]}
+    info = device_info(dev_index)
+    rows = rank_table(dist, world, rank, {
+        "rank": rank, "device": dev_index, "pci_bus_id": info["pci_bus_id"], "name": info["name"],
+        "hbm_free_gb": round(info["mem_free"] / 2 ** 30, 1), "hbm_total_gb": round(info["mem_total"] / 2 ** 30, 1),
+        "pairs": my_pairs, "ms_per_step": round((t1 - t0) / args.steps * 1e3, 3), "clock_ghz": round(clock_ghz, 3),
+        "result": summary})
+    gather_ms = (time.perf_counter() - tg0) * 1e3
     del out
 
     if rank == 0:
@@ -434,35 +531,48 @@ def main():
         iters, esz = reg.num_iterations, np.dtype(np_dtype).itemsize
         # with use_dog the Farneback inputs are the uint8 DOG images (1 B/px), not the level images
         fb_esz = 1 if reg.use_dog else esz
-        pristine = not args.size and not args.fused and not args.no_dog and args.dtype == "f32"
-        tps, tsrc = pmc_traffic(args.workload) if pristine else ({}, None)
+        pristine = (not args.size and not args.fused and not args.dog_fused and not args.no_dog and args.dtype == "f32"
+                    and not args.pairs_total and not args.feature_init)
+        tps, tsrc, tnote = pmc_traffic(args.workload) if pristine else ({}, None, "not the profiled command line")
         win = reg.overlap - (1 - reg.overlap % 2)
-        kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz, args.steps, tps, win // 2, tsrc)
+        nsteps_prof = args.steps * max(1, len(work))
+        kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz, nsteps_prof, tps, win // 2, tsrc,
+                                     clock_ghz, args.fused if k != "dog" else args.dog_fused, tnote)
                    for k, v in prof.items()}
         kernels = {k: v for k, v in kernels.items() if v}
         total_kernel_ms = sum(v["ms"] for v in prof.values())
         dominant = max(kernels, key=lambda k: prof[k]["ms"]) if kernels else None
         for k in kernels:
             kernels[k]["share_of_kernel_time"] = round(prof[k]["ms"] / total_kernel_ms, 4)
+        per = [r["ms_per_step"] for r in rows]
         res = {
-            "metric": METRIC, "value": round(world * H * W * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
+            "metric": METRIC, "value": round(pairs_per_step * H * W * args.steps / elapsed / 1e6, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "strong" if args.pairs_total else "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {wl['desc']}" + (f" (size overridden to {H})" if args.size else ""),
-                       "pairs_per_step": world, "tile_size": reg.tile_size, "overlap": reg.overlap,
+                       "pairs_per_step": pairs_per_step, "tile_size": reg.tile_size, "overlap": reg.overlap,
                        "num_iterations": reg.num_iterations, "muladd": "fma" if args.fused else "mul+add",
+                       "dog_muladd": "fma" if args.dog_fused else "mul+add",
                        "levels": [[r.factor, r.accepted] for r in reg.level_reports],
                        "devices": ndev, "affine_init": ("FeatureRegistrator" if freg is not None else
-                                                        "known matrix" if inv_affine is not None else None),
-                       "parallelism": f"{world} independent pairs, one rank per pair, {min(world, ndev)} GPU(s), no collective"},
+                                                        "known matrix" if wl.get("affine") else None),
+                       "parallelism": f"{pairs_per_step} independent pairs per step dealt round-robin to {world} rank(s), "
+                                      f"one rank per GPU, {min(world, ndev)} GPU(s), no collective on the data path"},
             "roofline": kernels.get(dominant),
             "roofline_polyexp": kernels.get("polyexp_m0"),
             "kernels": kernels,
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 3),
+            "sustained_clock_ghz": round(clock_ghz, 3),
+            "library": ctx.lib.ma_version().decode(),
+            "ranks": rows,
+            "rank_ms_per_step": {"min": min(per), "mean": round(sum(per) / len(per), 3), "max": max(per)},
+            "gather_ms": round(gather_ms, 3),
         }
-        if world == 1 and not args.fused and not args.no_variants:
+        if keep_host and not args.fused:
             res["variants"] = {}
+            dref, dmov, inv_affine, _ = work[0]
             # informational: the drop-in API as the reference's callers use it, numpy in -> numpy out (PCIe inclusive;
             # never the headline value)
             th = host_inclusive_leg(max(1, min(args.steps, 3)), ref, mov if inv_affine is None else
@@ -474,19 +584,31 @@ def main():
                                                  "what": "numpy in -> numpy out, the reference's statements: H2D of ref and mov, register(), D2H of the "
                                                          "flow, Warper.warp(mov, flow) (both recognised as resident: no second upload), D2H of "
                                                          "the warped image"}
+
+            def timed_steps():
+                step()
+                ctx.sync()
+                tf0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                ctx.sync()
+                return (time.perf_counter() - tf0) / args.steps
+
             # informational: the same workload with the window blur in the FMA rounding model
             # (MA_FB_MULADD_FUSED: OpenCV builds whose v_muladd is a fused multiply-add); not the headline value
             reg.muladd_fused = True
-            step()
-            ctx.sync()
-            tf0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            ctx.sync()
-            tf = (time.perf_counter() - tf0) / args.steps
+            tf = timed_steps()
             reg.muladd_fused = False
             res["variants"]["muladd_fma"] = {"value": round(H * W / tf / 1e6, 2), "unit": "Mpix/s",
                                              "ms_per_step": round(tf * 1e3, 3)}
+            if reg.use_dog and not args.dog_fused:
+                # informational: the dog() chain in the rounding model of OpenCV's AVX2 + FMA3 objects
+                reg.dog_muladd_fused = True
+                td = timed_steps()
+                reg.dog_muladd_fused = False
+                res["variants"]["dog_fma"] = {"value": round(H * W / td / 1e6, 2), "unit": "Mpix/s",
+                                              "ms_per_step": round(td * 1e3, 3),
+                                              "what": "dog() with fused multiply-adds (MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE)"}
             if args.lanes > 1 and inv_affine is None:
                 # informational: `lanes` independent pairs in flight on this GPU, one context (HIP stream, workspace)
                 # and one host thread per lane -- what parallel.register_pairs(lanes=...) does for a list of pairs
@@ -494,8 +616,9 @@ def main():
                 res["variants"][f"lanes{args.lanes}"] = {
                     "value": round(H * W / tl / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(tl * 1e3, 3),
                     "pairs_in_flight": args.lanes}
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, H), params)
+        if world == 1 and not args.no_cpu_baseline and not args.pairs_total:
+            sample = args.cpu_sample or (H if (os.cpu_count() or 1) >= 128 else 4096)
+            res["cpu_baseline"] = cpu_baseline(min(sample, H), params)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -79,6 +79,16 @@ int ma_ctx_trim(ma_ctx* ctx);
  * check that a loop such as warp_and_save_pages (__main__.py:288-302) uploads its flow once, not once per page. */
 int ma_ctx_transfer_stats(ma_ctx* ctx, unsigned long long* h2d_bytes, unsigned long long* d2h_bytes, int reset);
 
+/* Identity of a device, for the per-rank lines of a multi-GPU run: marketing name, PCI bus id ("0000:c1:00.0"), free
+ * and total HBM in bytes, compute units.  Any output pointer may be NULL.  Needs no ctx. */
+int ma_device_info(int device, char* name, size_t name_len, char* pci_bus_id, size_t pci_len, size_t* mem_free,
+                   size_t* mem_total, int* compute_units);
+/* Shader clock (GHz) the chip sustains under a packed-FP32 load with the instruction mix of the window-blur kernels
+ * (v_pk_add / v_pk_mul / v_pk_add, 4 waves per SIMD on every CU) for about `milliseconds`: s_memtime against the
+ * 100 MHz s_memrealtime, median over the blocks.  bench.py prices the VALU-bound kernels against the peak at THIS
+ * clock, measured in the same run, next to the 2.4 GHz nominal one.  Synchronises. */
+int ma_clock_probe(ma_ctx* ctx, double milliseconds, double* sustained_ghz);
+
 /* ---- device memory (caller owns host buffers; library owns nothing it returns
  *      except the error string) ------------------------------------------- */
 int ma_malloc(ma_ctx* ctx, size_t bytes, void** dptr);

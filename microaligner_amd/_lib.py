@@ -93,6 +93,8 @@ SIGNATURES.update({
     "ma_optflow_register": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(MaParams), _vp, C.POINTER(MaLevelReport), _i,
                                  C.POINTER(_i)]),
     "ma_host_np_mean": (_i, [C.POINTER(_d), C.c_long, C.POINTER(_d)]),
+    "ma_device_info": (_i, [_i, C.c_char_p, _sz, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i)]),
+    "ma_clock_probe": (_i, [_vp, _d, C.POINTER(_d)]),
 })
 
 _lib = None
@@ -114,6 +116,12 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def source_hash():
+    """Hash of the kernel sources the loaded library was built from (the `src:` field of ma_version())."""
+    v = load().ma_version().decode()
+    return v.split("src:", 1)[1].strip() if "src:" in v else None
 
 
 def check(rc):

@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmicroaligner_hip.so")
-SOURCES = ["ma_api.hip", "farneback.hip", "remap.hip", "pyramid.hip", "dog.hip", "nmi.hip", "affine.hip", "knn.hip", "daisy.hip", "register.hip"]
+SOURCES = ["ma_api.hip", "farneback.hip", "remap.hip", "pyramid.hip", "dog.hip", "nmi.hip", "affine.hip", "knn.hip", "daisy.hip", "register.hip", "probe.hip"]
 HEADERS = [os.path.join(CSRC, "ma_internal.h"), os.path.join(HERE, "..", "include", "microaligner_hip.h")]
 # -fno-slp-vectorize: the SLP vectoriser packs the sliding-window blur into v_pk_* ops with a storm of
 # register-pair shuffles (measured 1.65x slower on blur_h_solve, profiles/r01_*); packed math is written by hand
@@ -42,18 +42,37 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over every kernel source, the internal header, the public header and the compiler
+    flags: ma_version() carries it, the profile summaries under profiles/ record it, and bench.py only quotes PMC
+    traffic from a summary whose hash is the loaded library's."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(open(path, "rb").read())
+    h.update(" ".join(_flags()).encode())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link the shared library in-tree."""
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
+    # the source hash reaches ma_version() through a generated header that is rewritten only when it changes
+    hash_h = os.path.join(objdir, "ma_src_hash.h")
+    text = f'#define MA_SRC_HASH "{source_hash()}"\n'
+    if not os.path.exists(hash_h) or open(hash_h).read() != text:
+        with open(hash_h, "w") as f:
+            f.write(text)
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src] + HEADERS):
-            jobs.append([hipcc] + _flags() + ["-c", src, "-o", obj])
+        deps = [src] + HEADERS + ([hash_h] if s == "ma_api.hip" else [])
+        if force or _stale(obj, deps):
+            jobs.append([hipcc] + _flags() + ["-I", objdir, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

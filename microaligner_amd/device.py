@@ -353,6 +353,12 @@ class Context:
     def sync(self):
         L.check(self.lib.ma_sync(self.handle))
 
+    def clock_probe(self, milliseconds=20.0):
+        """Sustained shader clock in GHz under a packed-FP32 load (ma_clock_probe)."""
+        ghz = C.c_double()
+        L.check(self.lib.ma_clock_probe(self.handle, float(milliseconds), C.byref(ghz)))
+        return ghz.value
+
     def forget_host_arrays(self):
         """Drop every recorded host <-> device pair (Context.asdevice() uploads afresh); device memory held only by the
         pairs goes back to the pool."""
@@ -719,3 +725,12 @@ def device_count():
     n = C.c_int()
     L.load().ma_device_count(C.byref(n))
     return n.value
+
+
+def device_info(device=0):
+    """dict(name, pci_bus_id, mem_free, mem_total, compute_units) of a device (ma_device_info)."""
+    name, pci = C.create_string_buffer(256), C.create_string_buffer(64)
+    free, total, cus = C.c_size_t(), C.c_size_t(), C.c_int()
+    L.check(L.load().ma_device_info(int(device), name, 256, pci, 64, C.byref(free), C.byref(total), C.byref(cus)))
+    return dict(name=name.value.decode(), pci_bus_id=pci.value.decode(), mem_free=free.value, mem_total=total.value,
+                compute_units=cus.value)

@@ -110,48 +110,63 @@ def _daisy_tables(daisy: Daisy):
     return halves, cos_sin, daisy.sample_offsets()
 
 
-def find_features_device(tile_list: Sequence[np.ndarray], ctx) -> List[Features]:
-    """find_features_parallelized with the dense work on the device, all tiles of the level in one batch: the FAST
-    score map with non-maximum suppression (ma_fast_nms) and the DAISY orientation layers, their three Gaussian
-    smoothings and the descriptor sampling (ma_daisy_describe).  The host keeps what is sparse: picking the
-    strongest corners of each tile.  Same keypoints, same descriptors as find_features (tests compare them)."""
+DEVICE_WORKSPACE_BYTES = 8 << 30   # budget for the DAISY cubes of one batch of tiles (4 cubes x 8 planes x P^2 float32 each)
+
+
+def _device_batches(n_tiles: int, P: int, budget: int) -> List[range]:
+    """Tile index ranges whose DAISY workspace (128 P^2 bytes per tile) fits `budget` and whose plane count fits a grid
+    dimension (8 planes per tile, 65535 blocks along z): a 25 000^2 level at tile_size 200 is 15 876 tiles."""
+    per_tile = 4 * 8 * P * P * 4
+    step = max(1, min(budget // per_tile, 65535 // 8))
+    return [range(s, min(s + step, n_tiles)) for s in range(0, n_tiles, step)]
+
+
+def find_features_device(tile_list: Sequence[np.ndarray], ctx, workspace_bytes: Optional[int] = None) -> List[Features]:
+    """find_features_parallelized with the dense work on the device, the tiles of the level in batches sized from a
+    workspace budget: the FAST score map with non-maximum suppression (ma_fast_nms) and the DAISY orientation layers,
+    their three Gaussian smoothings and the descriptor sampling (ma_daisy_describe).  The host keeps what is sparse:
+    picking the strongest corners of each tile.  Same keypoints, same descriptors as find_features (tests compare them);
+    like the reference, any image size works -- large levels just take more batches."""
     n_tiles = len(tile_list)
     if n_tiles == 0:
         return []
     limit = min(1000000 // n_tiles, 5000)
-    tiles = np.ascontiguousarray(np.stack([np.asarray(t) for t in tile_list]))
-    if tiles.dtype != np.uint8:
-        raise ValueError("FAST works on uint8 images (the DOG output)")
     feats = [Features() for _ in range(n_tiles)]
-    if tiles.shape[1] <= 2 * TILE_OVERLAP:
-        return feats
-    d_tiles = ctx.asdevice(tiles)
-    score = ctx.fast_nms(d_tiles, TILE_OVERLAP, threshold=1)
-    picked, kp_tile, kp_xy = {}, [], []
-    for t in range(n_tiles):
-        if tiles[t].max() == 0:
-            continue
-        ys, xs = np.nonzero(score[t])
-        if len(ys) == 0:
-            continue
-        resp = score[t][ys, xs]
-        order = np.argsort(-resp, kind="stable")[:limit]      # strongest first, row-major order among equals
-        picked[t] = (xs[order], ys[order], resp[order])
-        kp_tile.append(np.full(len(order), t, np.int32))
-        kp_xy.append(np.stack([xs[order], ys[order]], 1).astype(np.float64))
-    if not picked:
+    P = int(np.shape(tile_list[0])[0])
+    if P <= 2 * TILE_OVERLAP:
         return feats
     daisy = Daisy(radius=21, q_radius=3, q_theta=8, q_hist=8)
     halves, cos_sin, offsets = _daisy_tables(daisy)
-    des = ctx.daisy_describe(d_tiles, np.concatenate(kp_tile), np.concatenate(kp_xy), halves, cos_sin, offsets)
-    pos = 0
-    for t, (xs, ys, resp) in picked.items():
-        n = len(xs)
-        if n >= 3:
-            feats[t].pts = np.stack([xs, ys], 1).astype(np.float64)
-            feats[t].responses = resp.astype(np.float64)
-            feats[t].descriptors = des[pos:pos + n]
-        pos += n
+    budget = DEVICE_WORKSPACE_BYTES if workspace_bytes is None else int(workspace_bytes)
+    for batch in _device_batches(n_tiles, P, budget):
+        tiles = np.ascontiguousarray(np.stack([np.asarray(tile_list[t]) for t in batch]))
+        if tiles.dtype != np.uint8:
+            raise ValueError("FAST works on uint8 images (the DOG output)")
+        d_tiles = ctx.asdevice(tiles)
+        score = ctx.fast_nms(d_tiles, TILE_OVERLAP, threshold=1)
+        picked, kp_tile, kp_xy = {}, [], []
+        for k, t in enumerate(batch):
+            if tiles[k].max() == 0:
+                continue
+            ys, xs = np.nonzero(score[k])
+            if len(ys) == 0:
+                continue
+            resp = score[k][ys, xs]
+            order = np.argsort(-resp, kind="stable")[:limit]      # strongest first, row-major order among equals
+            picked[t] = (xs[order], ys[order], resp[order])
+            kp_tile.append(np.full(len(order), k, np.int32))
+            kp_xy.append(np.stack([xs[order], ys[order]], 1).astype(np.float64))
+        if not picked:
+            continue
+        des = ctx.daisy_describe(d_tiles, np.concatenate(kp_tile), np.concatenate(kp_xy), halves, cos_sin, offsets)
+        pos = 0
+        for t, (xs, ys, resp) in picked.items():
+            n = len(xs)
+            if n >= 3:
+                feats[t].pts = np.stack([xs, ys], 1).astype(np.float64)
+                feats[t].responses = resp.astype(np.float64)
+                feats[t].descriptors = des[pos:pos + n]
+            pos += n
     return feats
 
 

@@ -101,7 +101,94 @@ def test_oracle_warp_affine_known_answers():
     assert big.shape == (80, 100) and np.array_equal(big[::2, ::2][:40, :50], img)
 
 
+# ---- the independent oracle of the feature stage (oracle/feature_oracle.py) and what pins it -------------------------
+import os  # noqa: E402
+
+SK = np.load(os.path.join(os.path.dirname(__file__), "golden", "feature_skimage.npz"))
+
+
+@pytest.mark.parametrize("case", range(len(SK["cases"])))
+def test_feature_oracle_is_pinned_by_scikit_image_fixtures(case):
+    """oracle/feature_oracle.py against fixtures made with scikit-image 0.18.3 (the conda interpreter of the build
+    container, tests/golden/make_feature_skimage_golden.py): the set of pixels that pass the 9-of-16 segment test equals
+    corner_fast(n=9) exactly, and scikit-image's DAISY variant run on the oracle's smoothing / ring-geometry / layout
+    helpers reproduces skimage.feature.daisy to 1e-12 (float64 on both sides; a few additions differ in order)."""
+    from oracle import feature_oracle as FO
+    seed, _, _, _, t = SK["cases"][case]
+    seed, t = int(seed), int(t)
+    tile = SK[f"tile{seed}"]
+    exp = np.unpackbits(SK[f"fast{seed}"])[:tile.size].reshape(tile.shape).astype(bool)
+    assert np.array_equal(FO.fast_is_corner(tile, t), exp) and exp.sum() > 500
+    np.testing.assert_allclose(FO.daisy_skimage(tile, int(SK["step"])), SK[f"daisy{seed}"], rtol=0, atol=1e-12)
+    # the score is the largest threshold that keeps the corner: positive exactly on the corners, and every sampled corner
+    # passes the test at its score but not one above
+    score = FO.fast_score(tile, t)
+    assert np.array_equal(score > 0, exp)
+    ys, xs = np.nonzero(exp)
+    for y, x in list(zip(ys, xs))[::211]:
+        sc = int(score[y, x])
+        assert FO.fast_is_corner(tile, sc)[y, x] and not FO.fast_is_corner(tile, sc + 1)[y, x]
+
+
+def test_host_feature_code_equals_the_oracle():
+    """The product's host statement of the stage (feature_reg/sparse_cpu.py: FAST by sliding minima, DAISY on
+    scipy.ndimage) against the oracle's direct definitions: corner scores after non-maximum suppression identical,
+    descriptors identical to the last bit."""
+    from oracle import feature_oracle as FO
+    for seed in SK["cases"][:, 0].astype(int):
+        tile = SK[f"tile{seed}"]
+        exp = FO.fast_nms(FO.fast_score(tile, 1))
+        got = np.zeros_like(exp)
+        for k in SP.fast_detect(tile, threshold=1, nonmax=True):
+            got[int(k.pt[1]), int(k.pt[0])] = int(k.response)
+        assert np.array_equal(got, exp) and (exp > 0).sum() > 50
+        ys, xs = np.nonzero(exp)
+        pts = np.stack([xs, ys], 1).astype(np.float64)[::3]
+        pts[::2] += 0.37                              # off-grid points exercise the bilinear weights
+        des = SP.Daisy(radius=21, q_radius=3, q_theta=8, q_hist=8).compute(tile, [SP.KeyPoint((float(x), float(y))) for x, y in pts])
+        assert np.array_equal(des, FO.daisy_describe(tile, pts))
+
+
 # ---- GPU ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_device_features_equal_the_oracle(ctx):
+    """The dense kernels of the feature stage, batched over all tiles of a level (ma_fast_nms, ma_daisy_describe),
+    against the independent oracle of the stage (oracle/feature_oracle.py, pinned by scikit-image fixtures where a
+    third-party implementation exists): non-maximum-suppressed FAST score maps identical, keypoints, responses and
+    descriptors of every tile identical to the last bit.  Includes an all-zero tile and a constant one (no features)."""
+    from oracle import feature_oracle as FO
+    from microaligner_amd.feature_reg import feature_detection as FD
+    img = O.dog(synthetic.make_cells(560, 640, seed=13), True)
+    tiles, _ = TR.split_image_into_tiles(img, 250)
+    tiles.append(np.zeros_like(tiles[0]))
+    tiles.append(np.full_like(tiles[0], 7))
+    stack = np.ascontiguousarray(np.stack(tiles))
+    score = ctx.fast_nms(ctx.asdevice(stack), FD.TILE_OVERLAP, threshold=1)
+    checked = (0, 4, len(tiles) - 2, len(tiles) - 1)
+    maps = {t: FO.fast_detect(tiles[t], FD.TILE_OVERLAP, 1) for t in checked}
+    for t in checked:
+        assert np.array_equal(score[t], maps[t])
+    dev = FD.find_features_device(tiles, ctx)
+    assert len(dev) == len(tiles) and not dev[-1].is_valid() and not dev[-2].is_valid()
+    limit = min(1000000 // len(tiles), 5000)
+    for t in checked[:2]:
+        ys, xs = np.nonzero(maps[t])
+        order = np.argsort(-maps[t][ys, xs], kind="stable")[:limit]     # strongest first, row-major among equals
+        assert dev[t].is_valid() and len(dev[t].pts) == len(order) > 100
+        assert np.array_equal(dev[t].pts, np.stack([xs[order], ys[order]], 1).astype(np.float64))
+        assert np.array_equal(dev[t].responses, maps[t][ys, xs][order].astype(np.float64))
+        assert np.array_equal(dev[t].descriptors, FO.daisy_describe(tiles[t], dev[t].pts))
+    # batches sized from a workspace budget (a 25 000^2 level does not fit one): same features whatever the batch size
+    P = tiles[0].shape[0]
+    assert [list(r) for r in FD._device_batches(5, P, 2 * 128 * P * P)] == [[0, 1], [2, 3], [4]]
+    assert len(FD._device_batches(20000, 302, 1 << 50)) == 3            # 8 planes per tile, 65535 blocks along z
+    small = FD.find_features_device(tiles, ctx, workspace_bytes=3 * 128 * P * P)
+    for a, b in zip(dev, small):
+        assert a.is_valid() == b.is_valid()
+        if a.is_valid():
+            assert np.array_equal(a.pts, b.pts) and np.array_equal(a.descriptors, b.descriptors)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 @pytest.mark.parametrize("case", ["rot", "scale", "shift", "far"])

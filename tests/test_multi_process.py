@@ -59,6 +59,25 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["config"]["pairs_per_step"] == 2
 
 
+def test_bench_eight_ranks_report_per_rank_rows_and_deal_pairs_round_robin():
+    """What the driver's 8-GPU run exercises, without GPUs: eight ranks rendezvous, every rank contributes a row (its
+    time per step, device identity, the pairs it owns), rank 0 prints min / mean / max over the ranks; with --pairs-total
+    the 64 mosaic tiles of BASELINE cfg5 are dealt round-robin (strong scaling)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "0",
+                        "--dry-run", "--workload", "cfg5", "--pairs-total", "64"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 8 and res["config"]["pairs_per_step"] == 64
+    assert [row["rank"] for row in res["ranks"]] == list(range(8))
+    assert [row["pairs"] for row in res["ranks"]] == [list(range(r0, 64, 8)) for r0 in range(8)]
+    per = [row["ms_per_step"] for row in res["ranks"]]
+    assert res["rank_ms_per_step"] == {"min": min(per), "mean": sum(per) / 8, "max": max(per)}
+    assert abs(res["ms_per_step"] - max(per)) < 1e-9            # the headline time is the slowest rank's
+
+
 def test_bench_launcher_propagates_a_rank_failure():
     """Without a HIP device the ranks fail; the launcher must stop the survivors and exit non-zero, not hang."""
     from microaligner_amd import device

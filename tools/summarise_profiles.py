@@ -62,7 +62,10 @@ for k, v in traffic.items():
     if g:
         groups[g]["hbm_bytes"] += v["fetch_bytes_x2"] + v["write_bytes"]
 steps = 3  # --steps 2 --warmup 1
-json.dump({"command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants (cfg3)", "steps_profiled": steps,
+sys.path.insert(0, root)
+from microaligner_amd import _lib  # noqa: E402
+json.dump({"kernel_source_hash": _lib.source_hash(), "library": _lib.load().ma_version().decode(),
+           "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants (cfg3)", "steps_profiled": steps,
            "note": "FETCH_SIZE*2 + WRITE_SIZE (KiB -> bytes), per MI355X_MICROARCH.md HBM section; separate --pmc passes",
            "per_kernel": traffic,
            "per_bench_group_bytes_per_step": {g: v["hbm_bytes"] / steps for g, v in groups.items()}},
