@@ -382,6 +382,26 @@ def test_nmi_special_cases(ctx):
     assert abs(ctx.nmi_scores(dr, dr)[0] - 1.0) < 1e-12
 
 
+def test_gate_accepts_the_unchanged_float_image_the_reference_dog_returns(ctx):
+    """A float image whose maximum is 0 but which is not all zero comes out of the reference's dog() unchanged
+    (optflow_registrator.py:256-257) and scikit-learn then labels its raw values: the gate takes that input too."""
+    import warnings
+    from sklearn.metrics import normalized_mutual_info_score as nmi
+    from microaligner_amd import OptFlowRegistrator
+    from microaligner_amd.shared_modules.similarity_scoring import check_if_higher_similarity, mi_tiled
+    rng = np.random.default_rng(4)
+    neg = -np.round(rng.random((90, 70)) * 5).astype(np.float32)       # max() == 0, values in {-5 .. 0}
+    other = -np.round(rng.random((90, 70)) * 3).astype(np.float32)
+    reg = OptFlowRegistrator()
+    assert reg.dog(neg, True) is neg
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert abs(mi_tiled(neg, other, 1000) - nmi(neg.ravel(), other.ravel())) < 1e-14
+        exp = np.mean([nmi(neg.ravel()[s:s + 400], other.ravel()[s:s + 400]) for s in range(0, neg.size, 400)])
+    assert abs(mi_tiled(neg, other, 20) - exp) < 1e-14
+    assert check_if_higher_similarity(neg, neg, other, 1000, verbose=False) == [True]
+
+
 def test_mi_tiled_host_function(ctx):
     from microaligner_amd.shared_modules.similarity_scoring import mi_tiled, check_if_higher_similarity
     ref, mov = pair(260, 250, 3)

@@ -161,3 +161,22 @@ def test_resident_cache_recognises_unmodified_host_arrays_only():
     d.ptr = None
     c.remember(a, d)
     assert c.lookup(a) is None                                            # a freed device array is never handed out
+
+
+def test_nmi_of_raw_labels_is_scikit_learns():
+    """The host path of the gate for label images that are not uint8 (a float image with max() == 0 leaves the reference's
+    dog() unchanged and scikit-learn labels its distinct values): identical to normalized_mutual_info_score."""
+    import warnings
+    import numpy as np
+    from sklearn.metrics import normalized_mutual_info_score as nmi
+    from microaligner_amd.shared_modules.similarity_scoring import _nmi_of_labels
+    rng = np.random.default_rng(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for n in (50, 5000):
+            a = -rng.integers(0, 7, n).astype(np.float32) * 0.5
+            b = (a * 2 + rng.integers(0, 3, n)).astype(np.float32)
+            assert abs(_nmi_of_labels(a, b) - nmi(a, b)) < 1e-14
+            assert abs(_nmi_of_labels(a, a) - 1.0) < 1e-14
+        z = np.zeros(9)
+        assert _nmi_of_labels(z, z) == 1.0 == nmi(z, z) and _nmi_of_labels(z, np.arange(9.0)) == 0.0 == nmi(z, np.arange(9.0))

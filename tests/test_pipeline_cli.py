@@ -1,0 +1,125 @@
+"""The command-line pipeline: the reference's YAML schema and validation without a GPU, and -- on the
+GPU -- a small three-cycle run from .npy stacks, compared with the same pipeline composed from the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import yaml
+
+from microaligner_amd import pipeline as P, synthetic
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REG = dict(NumberPyramidLevels=2, NumberIterationsPerLevel=3, TileSize=150, Overlap=30, NumberOfWorkers=0,
+           UseFullResImage=True, UseDOG=False)
+
+
+def config(tmp_path, paths, **over):
+    cfg = {"Input": {"InputImagePaths": paths, "ReferenceCycle": 1, "ReferenceChannel": "0"},
+           "Output": {"OutputDir": str(tmp_path / "out"), "OutputPrefix": "exp_", "SaveOutputToCycleStack": True},
+           "RegistrationParameters": {"OptFlowReg": dict(REG)}}
+    for k, v in over.items():
+        sec, key = k.split("__")
+        if v is None:
+            cfg[sec].pop(key)
+        else:
+            cfg[sec][key] = v
+    path = tmp_path / "config.yaml"
+    path.write_text(yaml.safe_dump(cfg))
+    return path
+
+
+def test_config_schema_and_validation(tmp_path):
+    """config_reader.py:76-97,154-260: same fields, same bounds, same messages."""
+    paths = {"Cycle 1": "a.npy", "Cycle 2": "b.npy"}
+    cfg = P.read_config(config(tmp_path, paths))
+    assert cfg.paths == {1: P.Path("a.npy"), 2: P.Path("b.npy")} and cfg.ref_cycle == 1 and cfg.ref_channel == "0"
+    assert cfg.feature is None and cfg.optflow.optflow_kwargs() == dict(num_pyr_lvl=2, num_iterations=3, tile_size=150,
+                                                                         use_full_res_img=True, use_dog=False, overlap=30)
+    # the shipped example of the reference parses (config_examples/config_1.yaml keys)
+    example = {"Input": {"InputImagePaths": {"Cycle 1": "img_path", "Cycle 2": "img_path2"}, "ReferenceCycle": 1,
+                         "ReferenceChannel": "DAPI"},
+               "Output": {"OutputDir": "/tmp/x", "OutputPrefix": "experiment_001_", "SaveOutputToCycleStack": True},
+               "RegistrationParameters": {"FeatureReg": dict(REG, TileSize=1000, Overlap=100, NumberPyramidLevels=3, UseDOG=True,
+                                                             UseFullResImage=False),
+                                          "OptFlowReg": dict(REG, TileSize=1000, Overlap=100, NumberPyramidLevels=3)}}
+    c = P.PipelineConfig(example)
+    assert c.feature.feature_kwargs()["use_dog"] is True and c.optflow.Overlap == 100 and c.to_stack
+    with pytest.raises(ValueError, match="These fields are absent"):
+        P.PipelineConfig({"Input": {}})
+    with pytest.raises(KeyError, match="Field ReferenceChannel is absent"):
+        P.read_config(config(tmp_path, paths, Input__ReferenceChannel=None))
+    with pytest.raises(ValueError, match="smaller than minimum: 1"):
+        P.read_config(config(tmp_path, paths, Input__ReferenceCycle=0))
+    with pytest.raises(ValueError, match="Cycle names in config file should follow pattern Cycle N"):
+        P.read_config(config(tmp_path, {"First": "a.npy"}))
+    for key, val, exc, msg in (("TileSize", 10, ValueError, "smaller than minimum: 20"),
+                               ("Overlap", 500, ValueError, "greater than maximum: 150"),
+                               ("NumberPyramidLevels", 9, ValueError, "greater than maximum: 8"),
+                               ("UseDOG", "yes", TypeError, "Field UseDOG has wrong data type"),
+                               ("NumberIterationsPerLevel", 0, ValueError, "smaller than minimum: 1")):
+        with pytest.raises(exc, match=msg):
+            P.read_config(config(tmp_path, paths, RegistrationParameters__OptFlowReg=dict(REG, **{key: val})))
+    with pytest.raises(ValueError, match="At least one of the registration methods"):
+        P.read_config(config(tmp_path, paths, RegistrationParameters__OptFlowReg=None))
+    with pytest.raises(NotImplementedError, match="CycleBuilder"):
+        P.read_config(config(tmp_path, {"Cycle 1": {"DAPI": "a.tif"}}))
+
+
+def test_stack_io_and_channel_lookup(tmp_path):
+    a = np.arange(2 * 3 * 4 * 5, dtype=np.uint16).reshape(2, 3, 4, 5)
+    np.save(tmp_path / "a.npy", a)
+    arr, names = P.read_stack(tmp_path / "a.npy")
+    assert arr.shape == (2, 3, 4, 5) and names == ["0", "1"] and np.array_equal(arr, a)
+    (tmp_path / "a.channels.json").write_text('["DAPI", "CD3"]')
+    assert P.read_stack(tmp_path / "a.npy")[1] == ["DAPI", "CD3"]
+    assert P.channel_index(["DAPI", "CD3"], "CD3", "x") == 1 and P.channel_index(["DAPI", "CD3"], "0", "x") == 0
+    with pytest.raises(ValueError, match="is not among the channels"):
+        P.channel_index(["DAPI"], "CD8", "cycle 2")
+    np.save(tmp_path / "b.npy", a[0, 0])
+    assert P.read_stack(tmp_path / "b.npy")[0].shape == (1, 1, 4, 5)
+    mm, path = P.create_output(tmp_path / "o.tif", (1, 2, 3, 4, 5), np.uint16, "npy")
+    mm[0] = a
+    mm.flush()
+    assert path.suffix == ".npy" and np.array_equal(np.load(path)[0], a)
+    if P._tifffile() is None:
+        with pytest.raises(RuntimeError, match="tifffile"):
+            P.read_stack(tmp_path / "img.tif")
+        with pytest.raises(RuntimeError, match="tifffile"):
+            P.create_output(tmp_path / "o.tif", (1, 1, 1, 4, 5), np.uint16, "tif")
+    r = subprocess.run([sys.executable, "-m", "microaligner_amd"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 2 and "usage" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_runs_the_cycle_chain_like_the_oracle_pipeline(tmp_path):
+    """Three cycles of (2 channels x 2 z planes) uint16 pages through `python -m microaligner_amd config.yaml`: the
+    written stack equals the reference pipeline composed from the oracle (max projection + normalisation, chained
+    registration, every page warped with its cycle's flow)."""
+    from oracle import oracle as O
+    from oracle import register_oracle as RO
+    H, W = 420, 380
+    cycles = []
+    for k in range(3):
+        ref, mov = synthetic.make_pair(H, W, seed=40 + k, dtype=np.uint16)
+        base = ref if k == 0 else mov
+        stack = np.stack([np.stack([base, (base // 2).astype(np.uint16)]), np.stack([(base // 3).astype(np.uint16), base[::-1].copy()])])
+        cycles.append(stack)
+        np.save(tmp_path / f"cyc{k + 1}.npy", stack)
+    cfg = config(tmp_path, {f"Cycle {k + 1}": str(tmp_path / f"cyc{k + 1}.npy") for k in range(3)})
+    r = subprocess.run([sys.executable, "-m", "microaligner_amd", str(cfg)], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out = np.load(tmp_path / "out" / "exp_optflow_reg_result_stack.npy")
+    assert out.shape == (1, 6, 2, H, W) and out.dtype == np.uint16
+    params = dict(num_pyr_lvl=2, num_iterations=3, tile_size=150, overlap=30, use_full_res_img=True, use_dog=False)
+    prep = lambda st: O.normalize_minmax_u8(np.maximum.reduce(list(st)).astype(np.float32))   # noqa: E731  utils.py:92-94
+    ref_img = prep(cycles[0][0])
+    assert np.array_equal(out[0, 0:2], cycles[0])
+    for k in (1, 2):
+        mov_img = prep(cycles[k][0])
+        flow, _ = RO.register(ref_img, mov_img, **params)
+        ref_img = RO.warp(mov_img, flow, 150, 30)
+        for c in range(2):
+            for z in range(2):
+                assert np.array_equal(out[0, 2 * k + c, z], RO.warp(cycles[k][c, z], flow, 150, 30)), (k, c, z)
