@@ -100,6 +100,23 @@ def pmc_traffic(workload):
     return summary.get("per_bench_group_bytes_per_step", {}), rel, None
 
 
+def kernel_clocks(workload):
+    """Effective shader clock per kernel group from the newest committed rocprofv3 summary (tools/kernel_clock.sh:
+    GRBM_GUI_ACTIVE / 8 / dispatch duration), quoted only when it was collected with the kernels that are loaded now.
+    The blur kernels hold a lower clock than ma_clock_probe's register-only load (they also drive LDS and HBM)."""
+    import glob
+    from microaligner_amd import _lib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_kernel_clocks_{workload}.json")))
+    if not files:
+        return {}, None
+    summary = json.load(open(files[-1]))
+    if summary.get("kernel_source_hash") != _lib.source_hash():
+        return {}, None
+    names = {"fb_blur_h_solve": "blur_h_solve", "fb_blur_v_stream": "blur_v", "fb_blur_v": "blur_v", "dog_fused": "dog"}
+    out = {names[k]: v["clock_ghz"] for k, v in summary.get("per_kernel", {}).items() if k in names}
+    return out, os.path.relpath(files[-1], ROOT)
+
+
 def valu_flops_per_px(kernel, winsize_taps, fused):
     """FP32 lane-operations per processed pixel of the VALU-bound kernels (what a perfect schedule must still issue).
     Window blurs: 5 planes x (k0 * c, then per tap pair add, multiply, add -- or add, fma).  DOG: two sigmas x (row
@@ -113,7 +130,7 @@ def valu_flops_per_px(kernel, winsize_taps, fused):
 
 
 def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsize_taps=0, traffic_source=None,
-                   clock_ghz=None, fused=False, traffic_note=None):
+                   clock_ghz=None, fused=False, traffic_note=None, kernel_clock=None, kernel_clock_source=None):
     if rec["launches"] == 0 or rec["ms"] <= 0:
         return None
     bpp = algorithmic_bytes_per_px(name, iters, esz)
@@ -140,12 +157,16 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
         # chip sustains under this instruction mix (ma_clock_probe, same run); the HBM view stays in `hbm`
         fpp = valu_flops_per_px(name, winsize_taps, fused)
         tf = fpp * rec["px"] / sec / 1e12
-        ghz = clock_ghz or NOMINAL_GHZ
+        # the clock this very kernel held (rocprofv3 summary of the loaded kernels) when there is one, else the probe's
+        ghz = kernel_clock or clock_ghz or NOMINAL_GHZ
         peak = VALU_LANES_PER_CLOCK * ghz * 1e9 / 1e12
         out.update({"bound": "valu", "achieved": round(tf, 2), "peak": round(peak, 2), "unit": "TFLOP/s",
                     "frac": round(tf / peak, 4), "peak_nominal": round(VALU_LANES_PER_CLOCK * NOMINAL_GHZ * 1e9 / 1e12, 2),
                     "frac_of_nominal": round(tf / (VALU_LANES_PER_CLOCK * NOMINAL_GHZ * 1e9 / 1e12), 4),
-                    "clock_ghz": round(ghz, 3), "clock_source": "ma_clock_probe, same run" if clock_ghz else "nominal",
+                    "clock_ghz": round(ghz, 3),
+                    "clock_source": (f"{kernel_clock_source} (GRBM_GUI_ACTIVE of this kernel)" if kernel_clock else
+                                     "ma_clock_probe, same run" if clock_ghz else "nominal"),
+                    "clock_probe_ghz": round(clock_ghz, 3) if clock_ghz else None,
                     "flops_per_px": fpp, "arithmetic": "fma" if fused else "mul+add (3 ops per tap pair)", "hbm": hbm})
     return out
 
@@ -536,8 +557,9 @@ def main():
         tps, tsrc, tnote = pmc_traffic(args.workload) if pristine else ({}, None, "not the profiled command line")
         win = reg.overlap - (1 - reg.overlap % 2)
         nsteps_prof = args.steps * max(1, len(work))
+        kclk, kclk_src = kernel_clocks(args.workload) if pristine else ({}, None)
         kernels = {k: roofline_entry(k, v, iters, fb_esz if k == "polyexp_m0" else esz, nsteps_prof, tps, win // 2, tsrc,
-                                     clock_ghz, args.fused if k != "dog" else args.dog_fused, tnote)
+                                     clock_ghz, args.fused if k != "dog" else args.dog_fused, tnote, kclk.get(k), kclk_src)
                    for k, v in prof.items()}
         kernels = {k: v for k, v in kernels.items() if v}
         total_kernel_ms = sum(v["ms"] for v in prof.values())

@@ -554,11 +554,14 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
         }
     };
     auto commit = [&]() {
+        // one predicate per column chunk (only the last chunk is partial), not one branch per store
 #pragma unroll
-        for (int k = 0; k < RW; k++)
+        for (int q = 0; q < Q; q++) {
+            if (lane + 64 * q < cols) {
 #pragma unroll
-            for (int q = 0; q < Q; q++)
-                if (lane + 64 * q < cols) lds[(w + NW * k) * lp + lane + 64 * q] = v[k][q];
+                for (int k = 0; k < RW; k++) lds[(w + NW * k) * lp + lane + 64 * q] = v[k][q];
+            }
+        }
     };
 
     float hs[5][R];

@@ -118,6 +118,35 @@ def test_c_level_loop_equals_the_python_level_loop(unrelated, dtype, params):
     assert np.array_equal(out["c"][0], exp) and [r[4] for r in out["c"][1]] == [r[3] for r in reports]
 
 
+def test_a_plain_c_host_drives_the_whole_path(tmp_path):
+    """tests/c_host/register_host.c: a C program that knows only include/microaligner_hip.h (compiled here with gcc, linked
+    against libmicroaligner_hip.so) registers and warps a pair through ma_optflow_register + ma_warp_tiled; its flow,
+    warped image and per-level reports equal the oracle's."""
+    import subprocess
+    from microaligner_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "register_host"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_host", "register_host.c"), "-o", str(exe), "-L", libdir,
+                    "-lmicroaligner_hip", f"-Wl,-rpath,{libdir}"], check=True, capture_output=True, text=True)
+    params = dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True, tile_size=180, overlap=36)
+    ref, mov = synthetic.make_pair(520, 610, seed=5, dtype=np.uint16)
+    ref.tofile(tmp_path / "ref.bin")
+    mov.tofile(tmp_path / "mov.bin")
+    r = subprocess.run([str(exe), "520", "610", "1", str(tmp_path / "ref.bin"), str(tmp_path / "mov.bin"),
+                        str(tmp_path / "flow.bin"), str(tmp_path / "warped.bin"), "2", "1", "1", "180", "36"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    flow = np.fromfile(tmp_path / "flow.bin", np.float32).reshape(520, 610, 2)
+    warped = np.fromfile(tmp_path / "warped.bin", np.uint16).reshape(520, 610)
+    exp, reports = RO.register(ref, mov, **params)
+    assert np.array_equal(flow, exp) and np.array_equal(warped, RO.warp(mov, exp, 180, 36))
+    lines = [ln.split() for ln in r.stdout.strip().splitlines()]
+    assert [(int(l[0]), int(l[5]) == 1) for l in lines] == [(rep[0], rep[3]) for rep in reports]
+    np.testing.assert_allclose([[float(l[3]), float(l[4])] for l in lines], [rep[1:3] for rep in reports], rtol=0, atol=1e-12)
+
+
 def test_c_register_errors():
     reg = make_reg(dict(num_pyr_lvl=3))
     reg.ref_img = reg.mov_img = np.ones((150, 150), np.float32)      # no level keeps 100 px

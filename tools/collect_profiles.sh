@@ -13,3 +13,5 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format csv -- $CMD > $OUT/b
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch --output-format csv -- $CMD > /dev/null 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write --output-format csv -- $CMD > /dev/null 2> $OUT/write.err
 python3 tools/summarise_profiles.py $OUT $TAG
+# gpurun only brings gpurun_out/ back: leave copies of the summaries there (commit them under profiles/ from the build container)
+mkdir -p $OUT/summary && cp profiles/${TAG}_kernel_stats_cfg3.csv profiles/${TAG}_hbm_traffic_cfg3.json $OUT/summary/
