@@ -308,6 +308,17 @@ int ma_knn2_l2(ma_ctx* ctx, const float* query, int nq, const float* train, int 
  * cv.FastFeatureDetector_create(threshold, True, TYPE_9_16).detect() returns, with their responses.
  * tiles: (nt, P, P) uint8; score_out: (nt, P-2*margin, P-2*margin) int32, 0 = no keypoint. */
 int ma_fast_nms(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int margin, int threshold, int* score_out);
+/* The same detector followed by the reference's selection (feature_detection.py:105-106: sorted by response, strongest
+ * first, Python's stable sort keeping row-major order among equals, cut to nfeatures_limit) on the device: kp_out
+ * (device, nt x limit x 3 int32) receives (x, y, response) per keypoint in interior coordinates, counts_host[t] how
+ * many of tile t's `limit` slots are filled.  limit <= 8192.  Synchronises (the counts). */
+int ma_fast_keypoints(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int margin, int threshold, int limit, int* kp_out,
+                      int* counts_host);
+/* split_image_into_tiles (tile_registration.py:27-34, slicer.py:69-118) for a uint8 device image: the n_tiles windows
+ * first_tile .. of the row-major tile grid, each (tile + 2*overlap)^2, zero outside the image, into tiles_out
+ * (n_tiles, P, P). */
+int ma_cut_tiles_u8(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int first_tile, int n_tiles,
+                    uint8_t* tiles_out);
 /* ma_daisy_describe: DAISY descriptors (radius 21, 3 rings x 8 locations + centre, 8 orientation bins = 200 floats,
  * no normalisation, bilinear sampling; feature_detection.py:107-110) at nkp keypoints.  tiles: (nt, P, P) uint8 or
  * float32 (device).  weights_host[c] / radii[c]: centre-first half of the c-th incremental Gaussian kernel (host

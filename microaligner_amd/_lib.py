@@ -93,6 +93,8 @@ SIGNATURES.update({
     "ma_optflow_register": (_i, [_vp, _vp, _vp, _i, _i, _i, C.POINTER(MaParams), _vp, C.POINTER(MaLevelReport), _i,
                                  C.POINTER(_i)]),
     "ma_host_np_mean": (_i, [C.POINTER(_d), C.c_long, C.POINTER(_d)]),
+    "ma_fast_keypoints": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(_i)]),
+    "ma_cut_tiles_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ma_device_info": (_i, [_i, C.c_char_p, _sz, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i)]),
     "ma_clock_probe": (_i, [_vp, _d, C.POINTER(_d)]),
 })

@@ -138,9 +138,189 @@ __global__ __launch_bounds__(256) void daisy_sample_kernel(const float* __restri
     }
 }
 
+
+// ---- feature tiles cut on the device (tile_registration.py:27-34 / slicer.py:69-118 for a uint8 image) ----------------------
+// tile t = (ty, tx) in row-major order; its window starts at (ty*T - ov, tx*T - ov) and is zero outside the image
+__global__ __launch_bounds__(256) void cut_tiles_kernel(const uint8_t* __restrict__ img, int H, int W, int T, int ov, int ntx,
+                                                        int P, int t0, uint8_t* __restrict__ tiles)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, t = blockIdx.z;
+    if (x >= P) return;
+    const int tile = t0 + t, ty = tile / ntx, tx = tile - ty * ntx;
+    const int iy = ty * T - ov + y, ix = tx * T - ov + x;
+    uint8_t v = 0;
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = img[(size_t)iy * W + ix];
+    tiles[((size_t)t * P + y) * P + x] = v;
+}
+
+// ---- keypoint selection on the device ------------------------------------------------------------------------------
+// feature_detection.py:105-106: the corners of a tile sorted by response, strongest first (Python's stable sort keeps
+// the detector's row-major order among equal responses), cut to the per-tile limit.  One block per tile over the
+// non-maximum-suppressed score map:
+//   A. histogram of the scores (1 .. 254) -> the cut-off score s* and how many corners of exactly that score still fit;
+//   B. one ordered pass (row-major chunks, block scans) collects every corner above s* and the first `need_eq` of the
+//      corners at s* into LDS as keys (65535 - score) << 32 | row-major index;
+//   C. bitonic sort of the <= 8192 keys in LDS: ascending key = descending score, row-major among equals.
+constexpr int KS_T = 1024, KS_E = 8, KS_CAP = 8192;
+
+__device__ __forceinline__ int ks_block_exscan(int v, int* wsum, int& total)
+{
+    // exclusive scan of one int per thread over the 1024-thread block; total = block sum (all threads)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int n = __shfl_up(inc, off);
+        if (lane >= off) inc += n;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < KS_T / 64; k++) {
+        const int sk = wsum[k];
+        if (k < wv) base += sk;
+        tot += sk;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(KS_T) void kp_select_kernel(const int* __restrict__ score, int Pi, int limit, int* __restrict__ kp_out,
+                                                        int* __restrict__ counts)
+{
+    __shared__ unsigned long long keys[KS_CAP];
+    __shared__ int hist[256];
+    __shared__ int wsum[KS_T / 64];
+    __shared__ int cut[3];   // s*, need_eq, n_sel
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int* s = score + (size_t)t * Pi * Pi;
+    const int n = Pi * Pi;
+    for (int i = tid; i < 256; i += KS_T) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += KS_T) {
+        const int v = s[i];
+        if (v > 0) atomicAdd(&hist[v < 255 ? v : 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int total = 0;
+        for (int k = 1; k < 256; k++) total += hist[k];
+        int sstar = 0, need_eq = 0;
+        if (total > limit) {
+            int gt = 0;
+            for (int k = 255; k >= 1; k--) {
+                if (gt + hist[k] > limit) { sstar = k; need_eq = limit - gt; break; }
+                gt += hist[k];
+            }
+        }
+        cut[0] = sstar; cut[1] = need_eq; cut[2] = total < limit ? total : limit;
+    }
+    __syncthreads();
+    const int sstar = cut[0], need_eq = cut[1], n_sel = cut[2];
+    int eq_base = 0, sel_base = 0;
+    for (int c0 = 0; c0 < n; c0 += KS_T * KS_E) {
+        const int i0 = c0 + tid * KS_E;
+        int v[KS_E], neq = 0;
+#pragma unroll
+        for (int e = 0; e < KS_E; e++) {
+            v[e] = i0 + e < n ? s[i0 + e] : 0;
+            neq += (sstar > 0 && v[e] == sstar) ? 1 : 0;
+        }
+        int eq_total;
+        int eq_rank = eq_base + ks_block_exscan(neq, wsum, eq_total);
+        int nsel = 0;
+        bool take[KS_E];
+#pragma unroll
+        for (int e = 0; e < KS_E; e++) {
+            bool tk = v[e] > sstar;                              // sstar == 0: every corner
+            if (sstar > 0 && v[e] == sstar) { tk = eq_rank < need_eq; eq_rank++; }
+            take[e] = tk;
+            nsel += tk ? 1 : 0;
+        }
+        int sel_total;
+        int pos = sel_base + ks_block_exscan(nsel, wsum, sel_total);
+#pragma unroll
+        for (int e = 0; e < KS_E; e++)
+            if (take[e]) keys[pos++] = ((unsigned long long)(65535 - v[e]) << 32) | (unsigned)(i0 + e);
+        eq_base += eq_total;
+        sel_base += sel_total;
+    }
+    __syncthreads();
+    int m = 1;
+    while (m < n_sel) m <<= 1;
+    for (int i = n_sel + tid; i < m; i += KS_T) keys[i] = ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m; i += KS_T) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = keys[i], b = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n_sel; i += KS_T) {
+        const unsigned long long key = keys[i];
+        const int idx = (int)(key & 0xffffffffu), sc = 65535 - (int)(key >> 32);
+        int* o = kp_out + ((size_t)t * limit + i) * 3;
+        o[0] = idx % Pi; o[1] = idx / Pi; o[2] = sc;
+    }
+    if (tid == 0) counts[t] = n_sel;
+}
+
 } // namespace
 
 extern "C" {
+
+int ma_cut_tiles_u8(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int first_tile, int n_tiles,
+                    uint8_t* tiles_out)
+{
+    MA_REQUIRE(ctx && img && tiles_out, "NULL argument");
+    MA_REQUIRE(H > 0 && W > 0 && tile > 0 && overlap >= 0 && first_tile >= 0 && n_tiles >= 1 && n_tiles <= 65535, "bad tile geometry");
+    const int ntx = (W + tile - 1) / tile, nty = (H + tile - 1) / tile, P = tile + 2 * overlap;
+    MA_REQUIRE(first_tile + n_tiles <= ntx * nty && P <= 65535, "tile range out of bounds");
+    MA_HIP(hipSetDevice(ctx->device));
+    MaProfScope ps(ctx, MA_K_OTHER, (double)n_tiles * P * P);
+    hipLaunchKernelGGL(cut_tiles_kernel, dim3((P + 255) / 256, P, n_tiles), dim3(256), 0, ctx->stream, img, H, W, tile, overlap,
+                       ntx, P, first_tile, tiles_out);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+int ma_fast_keypoints(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int margin, int threshold, int limit, int* kp_out,
+                      int* counts_host)
+{
+    MA_REQUIRE(ctx && tiles && kp_out && counts_host, "NULL argument");
+    MA_REQUIRE(nt >= 1 && nt <= 65535 && margin >= 0 && P - 2 * margin >= 1 && P - 2 * margin <= 46340, "bad tile geometry");
+    MA_REQUIRE(limit >= 1 && limit <= KS_CAP, "limit must be in [1, 8192]");
+    MA_REQUIRE(threshold >= 0 && threshold < 254, "bad threshold");
+    MA_HIP(hipSetDevice(ctx->device));
+    const int Pi = P - 2 * margin;
+    const size_t map = (size_t)nt * Pi * Pi * sizeof(int);
+    MA_TRY(ma_ws_reserve(ctx, 2 * map + (size_t)nt * sizeof(int)));
+    MA_TRY(ma_pinned_reserve(ctx, (size_t)nt * sizeof(int)));
+    int* raw = (int*)ctx->ws;
+    int* nms = raw + (size_t)nt * Pi * Pi;
+    int* counts = nms + (size_t)nt * Pi * Pi;
+    {
+        MaProfScope ps(ctx, MA_K_OTHER, (double)nt * Pi * Pi);
+        const dim3 grid((Pi + 255) / 256, Pi, nt);
+        hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, ctx->stream, tiles, P, margin, threshold, raw);
+        hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, ctx->stream, (const int*)raw, Pi, nms);
+        hipLaunchKernelGGL(kp_select_kernel, dim3(nt), dim3(KS_T), 0, ctx->stream, (const int*)nms, Pi, limit, kp_out, counts);
+        MA_HIP(hipGetLastError());
+    }
+    MA_HIP(hipMemcpyAsync(ctx->pinned, counts, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < nt; t++) counts_host[t] = ((const int*)ctx->pinned)[t];
+    return MA_OK;
+}
 
 int ma_fast_nms(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int margin, int threshold, int* score_out)
 {

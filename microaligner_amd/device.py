@@ -605,22 +605,52 @@ class Context:
         return out
 
     def knn2(self, query, train):
-        """Exact 2-NN (L2) of every row of `query` among the rows of `train` (host arrays in, host arrays out):
-        (idx (n, 2) int64, dist (n, 2) float32) like feature_reg.sparse_cpu.knn2."""
-        q = np.ascontiguousarray(query, np.float32)
-        t = np.ascontiguousarray(train, np.float32)
-        if q.ndim != 2 or t.ndim != 2 or q.shape[1] != t.shape[1]:
-            raise ValueError("query and train must be 2-D with the same descriptor length")
-        pad = -q.shape[1] % 4
-        if pad:
-            q, t = np.pad(q, ((0, 0), (0, pad))), np.pad(t, ((0, 0), (0, pad)))
-        dq, dt = self.asdevice(q), self.asdevice(t)
+        """Exact 2-NN (L2) of every row of `query` among the rows of `train`: (idx (n, 2) int64, dist (n, 2) float32)
+        on the host, like feature_reg.sparse_cpu.knn2.  Either side may be a host array or a DeviceArray (descriptors
+        that ma_daisy_describe left on the device are searched where they are)."""
+        def prep(a):
+            if isinstance(a, DeviceArray):
+                if a.ndim != 2 or a.dtype != np.float32 or a.shape[1] % 4:
+                    raise ValueError("device descriptors must be (n, dim) float32 with dim a multiple of 4")
+                return a
+            a = np.ascontiguousarray(a, np.float32)
+            if a.ndim != 2:
+                raise ValueError("query and train must be 2-D")
+            pad = -a.shape[1] % 4
+            return self.asdevice(np.pad(a, ((0, 0), (0, pad))) if pad else a)
+        dq, dt = prep(query), prep(train)
+        if dq.shape[1] != dt.shape[1]:
+            raise ValueError("query and train must have the same descriptor length")
+        nq = dq.shape[0]
         # (the image dtypes of asdevice() do not include int32: raw buffers for the results)
-        idx, dist = self.empty((len(q), 2), np.float32), self.empty((len(q), 2), np.float32)
-        self._run(self.lib.ma_knn2_l2, dq.ptr, len(q), dt.ptr, len(t), q.shape[1], idx.ptr, dist.ptr)
-        out_i = np.empty((len(q), 2), np.int32)
+        idx, dist = self.empty((nq, 2), np.float32), self.empty((nq, 2), np.float32)
+        self._run(self.lib.ma_knn2_l2, dq.ptr, nq, dt.ptr, dt.shape[0], dq.shape[1], idx.ptr, dist.ptr)
+        out_i = np.empty((nq, 2), np.int32)
         L.check(self.lib.ma_memcpy_d2h(self.handle, out_i.ctypes.data, idx.ptr, out_i.nbytes))
         return out_i.astype(np.int64), np.sqrt(dist.numpy())   # the kernel returns squared distances
+
+    def cut_tiles(self, img, tile, overlap, first_tile, n_tiles):
+        """The zero-padded feature windows first_tile .. first_tile + n_tiles of a uint8 device image: (n, P, P)."""
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise ValueError("FAST works on uint8 images (the DOG output)")
+        H, W = img.shape
+        P = tile + 2 * overlap
+        out = self.empty((n_tiles, P, P), np.uint8)
+        self._run(self.lib.ma_cut_tiles_u8, img.ptr, H, W, int(tile), int(overlap), int(first_tile), int(n_tiles), out.ptr)
+        return out
+
+    def fast_keypoints(self, tiles, margin, limit, threshold=1):
+        """FAST-9/16 corners of every tile interior, strongest `limit` first (row-major among equals), selected on the
+        device: (counts (nt,), kp (nt, limit, 3) int32 = x, y, response; rows beyond counts[t] are undefined)."""
+        nt, P, P2 = tiles.shape
+        if P != P2 or tiles.dtype != np.uint8:
+            raise ValueError("FAST works on square uint8 tiles (the DOG output)")
+        out = self._raw(nt * limit * 3 * 4)
+        counts = (C.c_int * nt)()
+        self._run(self.lib.ma_fast_keypoints, tiles.ptr, nt, P, int(margin), int(threshold), int(limit), out.ptr, counts)
+        host = np.empty((nt, limit, 3), np.int32)
+        L.check(self.lib.ma_memcpy_d2h(self.handle, host.ctypes.data, out.ptr, host.nbytes))
+        return np.frombuffer(counts, np.int32).copy(), host
 
     def _raw(self, nbytes):
         """Untyped HBM buffer from the pool (results that are not image dtypes: int32 scores, float64 points)."""
@@ -645,8 +675,9 @@ class Context:
         L.check(self.lib.ma_memcpy_d2h(self.handle, host.ctypes.data, out.ptr, host.nbytes))
         return host
 
-    def daisy_describe(self, tiles, kp_tile, kp_xy, weights, cos_sin, offsets):
-        """DAISY descriptors at the given keypoints: (n, 200) float32 on the host (see ma_daisy_describe)."""
+    def daisy_describe(self, tiles, kp_tile, kp_xy, weights, cos_sin, offsets, on_device=False):
+        """DAISY descriptors at the given keypoints: (n, 200) float32 on the host, or left on the device (see
+        ma_daisy_describe)."""
         nt, P, _ = tiles.shape
         n = len(kp_tile)
         d_tile = self._upload_raw(np.asarray(kp_tile, np.int32))
@@ -660,7 +691,7 @@ class Context:
         self._run(self.lib.ma_daisy_describe, tiles.ptr, _dt(tiles.dtype), nt, P, wptr, radii,
                   cs.ctypes.data_as(C.POINTER(C.c_double)), of.ctypes.data_as(C.POINTER(C.c_double)), d_tile.ptr, d_xy.ptr,
                   n, desc.ptr)
-        return desc.numpy()
+        return desc if on_device else desc.numpy()
 
     def normalize_minmax_u8(self, arr):
         out = self.empty(arr.shape, np.uint8)

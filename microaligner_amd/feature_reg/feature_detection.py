@@ -27,7 +27,22 @@ class Features:
         self._keypoints: Optional[List[KeyPoint]] = None
         self.pts: Optional[np.ndarray] = None
         self.responses: Optional[np.ndarray] = None
-        self.descriptors: Optional[np.ndarray] = None
+        self._descriptors = None           # ndarray (n, 200) float32, or a DeviceArray that is downloaded when asked for
+
+    @property
+    def descriptors(self) -> Optional[np.ndarray]:
+        if self._descriptors is not None and not isinstance(self._descriptors, np.ndarray):
+            self._descriptors = self._descriptors.numpy()
+        return self._descriptors
+
+    @descriptors.setter
+    def descriptors(self, des):
+        self._descriptors = des
+
+    @property
+    def descriptors_for_search(self):
+        """The descriptors where they are (host array or DeviceArray): what the 2-NN search takes."""
+        return self._descriptors
 
     @property
     def keypoints(self) -> Optional[List[KeyPoint]]:
@@ -46,7 +61,7 @@ class Features:
             self.pts = self.responses = None
 
     def is_valid(self) -> bool:
-        return self.pts is not None and self.descriptors is not None
+        return self.pts is not None and self._descriptors is not None
 
 
 def view_tile_without_overlap(img, overlap):
@@ -80,11 +95,15 @@ def match_features(img1_features: Features, img2_features: Features, verbose: bo
     identity = np.eye(2, 3)
     if not img1_features.is_valid() or not img2_features.is_valid():
         return identity
-    pts1, des1 = img1_features.pts, img1_features.descriptors
-    pts2, des2 = img2_features.pts, img2_features.descriptors
+    search = knn or knn2
+    pts1, pts2 = img1_features.pts, img2_features.pts
+    if knn is not None:     # the device search takes the descriptors where they are
+        des1, des2 = img1_features.descriptors_for_search, img2_features.descriptors_for_search
+    else:
+        des1, des2 = img1_features.descriptors, img2_features.descriptors
     if len(des1) < 2:
         return identity
-    idx, dist = (knn or knn2)(des2, des1)
+    idx, dist = search(des2, des1)
     good = np.nonzero(dist[:, 0] < RATIO * dist[:, 1])[0]
     if verbose:
         print("    Good matches", len(good), "/", len(des2))
@@ -168,6 +187,45 @@ def find_features_device(tile_list: Sequence[np.ndarray], ctx, workspace_bytes: 
                 feats[t].descriptors = des[pos:pos + n]
             pos += n
     return feats
+
+
+def find_features_of_device_image(img, tile_size: int, ctx, workspace_bytes: Optional[int] = None):
+    """tile_registration.find_features for a uint8 image that is already on the device (the DOG output): the feature
+    windows are cut there (ma_cut_tiles_u8), the corners detected, ranked and cut to the per-tile limit there
+    (ma_fast_keypoints), the descriptors computed and LEFT there (ma_daisy_describe) for the 2-NN search.  Only the
+    selected keypoints -- a few thousand (x, y, response) triples per tile -- come back to the host.  Returns the
+    combined Features in image coordinates (combine_features' layout: tile by tile, strongest first within a tile)."""
+    from ..shared_modules.tiling import TileGrid
+    H, W = img.shape
+    grid = TileGrid(H, W, tile_size, TILE_OVERLAP)
+    n_tiles, P = grid.ntiles, grid.window
+    combined = Features()
+    if P <= 2 * TILE_OVERLAP:
+        return combined
+    limit = min(1000000 // n_tiles, 5000)
+    daisy = Daisy(radius=21, q_radius=3, q_theta=8, q_hist=8)
+    halves, cos_sin, offsets = _daisy_tables(daisy)
+    budget = DEVICE_WORKSPACE_BYTES if workspace_bytes is None else int(workspace_bytes)
+    pts, responses, descs = [], [], []
+    for batch in _device_batches(n_tiles, P, budget):
+        d_tiles = ctx.cut_tiles(img, tile_size, TILE_OVERLAP, batch[0], len(batch))
+        counts, kp = ctx.fast_keypoints(d_tiles, TILE_OVERLAP, limit, threshold=1)
+        keep = [k for k in range(len(batch)) if counts[k] >= 3]      # feature_detection.py:112-115
+        if not keep:
+            continue
+        kp_tile = np.concatenate([np.full(counts[k], k, np.int32) for k in keep])
+        kp_xy = np.concatenate([kp[k, :counts[k], :2] for k in keep]).astype(np.float64)
+        descs.append(ctx.daisy_describe(d_tiles, kp_tile, kp_xy, halves, cos_sin, offsets, on_device=True))
+        for k in keep:
+            t = batch[k]
+            origin = np.array([t % grid.nx * tile_size, t // grid.nx * tile_size], np.float64)
+            pts.append(kp[k, :counts[k], :2].astype(np.float64) + origin)
+            responses.append(kp[k, :counts[k], 2].astype(np.float64))
+    if pts:
+        combined.pts = np.concatenate(pts, axis=0)
+        combined.responses = np.concatenate(responses)
+        combined.descriptors = descs[0] if len(descs) == 1 else np.concatenate([d.numpy() for d in descs], axis=0)
+    return combined
 
 
 def find_features_parallelized(tile_list: Sequence[np.ndarray], workers: Optional[int] = None) -> List[Features]:

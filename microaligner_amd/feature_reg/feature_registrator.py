@@ -8,7 +8,6 @@ Division of labour: pyramid (cv2.pyrDown), dog(), the image tra
 on the host (feature_detection.py / sparse_cpu.py).  The public surface mirrors the reference; the machinery below it
 is this package's own: one `_Level` record per pyramid level, one `_register_level` pass per level.
 """
-import gc
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -18,7 +17,7 @@ from ..device import DeviceArray, get_context
 from ..shared_modules.img_checks import check_img_dims_match, check_img_is_2d_grey, check_img_is_provided
 from ..shared_modules.similarity_scoring import check_if_higher_similarity
 from . import affine_math
-from .feature_detection import Features
+from .feature_detection import Features, find_features_of_device_image
 from .tile_registration import find_features, register_img_pair
 
 
@@ -95,7 +94,6 @@ class FeatureRegistrator:
                 mov_level = self.transform_img(mov_level, so_far)
             level_mat = self._register_level(ref_level, mov_level)
             found.append(affine_math.with_translation_scaled(level_mat, factor))
-            gc.collect()
         return affine_math.compose(found)
 
     # -- image transforms -----------------------------------------------------------------------------------
@@ -145,9 +143,12 @@ class FeatureRegistrator:
     # -- one level ------------------------------------------------------------------------------------------
     def _features_of(self, img) -> Features:
         """Features of dog(img) (or of img itself with use_dog off): tiles cut on the host, dense work on the device."""
+        ctx = get_context()
         pre = self.dog(img, self.use_dog)
+        if isinstance(pre, DeviceArray) and pre.dtype == np.uint8:
+            return find_features_of_device_image(pre, self.tile_size, ctx)
         host = pre.numpy() if isinstance(pre, DeviceArray) else np.asarray(pre)
-        return find_features(host, self.tile_size, get_context())
+        return find_features(host, self.tile_size, ctx)
 
     def _register_level(self, ref_level: _Level, mov_level) -> np.ndarray:
         """:162-207: `num_iterations` rounds on one level.  A round estimates the similarity that maps the current

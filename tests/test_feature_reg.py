@@ -190,6 +190,58 @@ def test_device_features_equal_the_oracle(ctx):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,tile,dense", [((1130, 1210), 1000, True), ((700, 820), 300, False), ((260, 240), 200, False)])
+def test_keypoints_selected_on_the_device_equal_the_oracle_selection(ctx, shape, tile, dense):
+    """The route FeatureRegistrator takes: the DOG image stays on the device, the feature windows are cut there
+    (ma_cut_tiles_u8), the corners are detected, ranked and cut to the per-tile limit there (ma_fast_keypoints: histogram
+    cut-off, ordered collection, bitonic sort) and the descriptors stay there for the 2-NN search.  Against the oracle:
+    the reference's selection (strongest first, row-major among equal responses, nfeatures_limit) tile by tile -- the
+    dense case has ten times more corners than the limit of 5000 and thousands of ties at the cut-off score."""
+    from oracle import feature_oracle as FO
+    from microaligner_amd.feature_reg import feature_detection as FD
+    rng = np.random.default_rng(shape[0])
+    if dense:
+        from scipy.ndimage import gaussian_filter
+        img = gaussian_filter(rng.standard_normal(shape), 1.2)
+        img = np.round((img - img.min()) / (img.max() - img.min()) * 255).astype(np.uint8)
+    else:
+        img = O.dog(synthetic.make_cells(*shape, seed=shape[1]), True)
+    d_img = ctx.asdevice(img)
+    got = FD.find_features_of_device_image(d_img, tile, ctx)
+    tiles, info = TR.split_image_into_tiles(img, tile)
+    assert np.array_equal(ctx.cut_tiles(d_img, tile, FD.TILE_OVERLAP, 0, len(tiles)).numpy(), np.stack(tiles))
+    limit = min(1000000 // len(tiles), 5000)
+    pts, resp, des = [], [], []
+    for t, tl in enumerate(tiles[:4] if dense else tiles):
+        m = FO.fast_detect(tl, FD.TILE_OVERLAP, 1)
+        ys, xs = np.nonzero(m)
+        order = np.argsort(-m[ys, xs], kind="stable")[:limit]
+        if dense and t == 0:
+            assert len(ys) > 5 * limit and (m[ys, xs] == m[ys, xs][order][-1]).sum() > 50       # a real cut with ties
+        if len(order) < 3:
+            continue
+        origin = np.array([t % info["ntiles"]["x"] * tile, t // info["ntiles"]["x"] * tile], np.float64)
+        p = np.stack([xs[order], ys[order]], 1).astype(np.float64)
+        pts.append(p + origin)
+        resp.append(m[ys, xs][order].astype(np.float64))
+        des.append(FO.daisy_describe(tl, p[::7]))
+    n = sum(len(p) for p in pts)
+    assert got.is_valid() and len(got.pts) >= n
+    assert np.array_equal(got.pts[:n], np.concatenate(pts)) and np.array_equal(got.responses[:n], np.concatenate(resp))
+    pos, gdes = 0, got.descriptors
+    for p, d in zip(pts, des):
+        assert np.array_equal(gdes[pos:pos + len(p)][::7], d)
+        pos += len(p)
+    # the host-tile route gives the very same combined features
+    old = TR.find_features(img, tile, ctx)
+    assert np.array_equal(old.pts, got.pts) and np.array_equal(old.descriptors, got.descriptors)
+    # the 2-NN search takes the descriptors where they are
+    idx_d, dist_d = ctx.knn2(got.descriptors_for_search, got.descriptors_for_search)
+    idx_h, dist_h = ctx.knn2(old.descriptors, old.descriptors)
+    assert np.array_equal(idx_d, idx_h) and np.array_equal(dist_d, dist_h)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 @pytest.mark.parametrize("case", ["rot", "scale", "shift", "far"])
 def test_warp_affine_cv_bit_exact(ctx, dtype, case):
