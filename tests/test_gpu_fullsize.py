@@ -39,11 +39,16 @@ def _hip(ref, mov, params):
     return flow, reg.level_reports, w.warp()
 
 
-def _compare(ref, mov, params, label):
+def _compare(ref, mov, params, label, models=None):
+    """models: rounding models as (window blur fused, dog() chain fused); None = the defaults (SSE2 baseline)."""
+    hip_params, orc_params = dict(params), dict(params)
+    if models is not None:
+        hip_params.update(muladd_fused=models[0], dog_muladd_fused=models[1])
+        orc_params.update(fused=models[0], dog_flags=O.DOG_FUSED if models[1] else 0)
     t0 = time.perf_counter()
-    flow, reports, warped = _hip(ref, mov, params)
+    flow, reports, warped = _hip(ref, mov, hip_params)
     t1 = time.perf_counter()
-    exp_flow, exp_rep = RO.register(ref, mov, nthreads=CORES, **params)
+    exp_flow, exp_rep = RO.register(ref, mov, nthreads=CORES, **orc_params)
     exp_warp = RO.warp(mov, exp_flow, params.get("tile_size", 1000), params.get("overlap", 100))
     t2 = time.perf_counter()
     print(f"\n[{label}] HIP {t1 - t0:.2f} s (numpy in/out, cold), oracle {t2 - t1:.1f} s on {CORES} threads; levels "
@@ -65,6 +70,15 @@ def test_cfg2_register_and_warp_equal_the_oracle():
     dx, dy = synthetic.displacement(4096, 4096)
     err = np.abs(flow[300:-300, 300:-300] - np.stack([dx + 0 * dy, dy + 0 * dx], -1)[300:-300, 300:-300])
     assert err.mean() < 0.3
+
+
+def test_cfg2_size_with_dog_in_the_fma_rounding_models_equals_the_oracle():
+    """4096^2 float32 with DOG inputs, both the dog() chain and the Farneback window blur in their fused multiply-add
+    models (what an OpenCV build dispatching to AVX2 + FMA3 objects / built with FMA computes): every level's decisions,
+    MI scores, the flow and the warped image against the oracle in the same models, at a BASELINE size."""
+    ref, mov = synthetic.make_pair(4096, 4096, 3)
+    _compare(ref, mov, dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True), "4096^2 f32 + DOG, FMA models",
+             models=(True, True))
 
 
 @pytest.mark.skipif(not BIG_HOST, reason=f"the 8192^2 oracle run needs >= 64 host cores (this host: {CORES})")

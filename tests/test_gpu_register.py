@@ -160,6 +160,23 @@ def test_c_register_errors():
     reg.ref_img = reg.mov_img = np.ones((300, 300), np.float32)
     with pytest.raises(ValueError, match="cannot be less than 0"):
         reg.register()
+    # the C entry itself: a reports buffer that is too small, NULL arguments
+    import ctypes as C
+    from microaligner_amd import _lib as L
+    from microaligner_amd.device import get_context
+    ctx = get_context()
+    d = ctx.asdevice(np.ones((300, 300), np.float32))
+    flow = ctx.empty((300, 300, 2), np.float32)
+    prm = L.MaParams()
+    ctx.lib.ma_params_default(C.byref(prm))
+    reps, n = (L.MaLevelReport * 1)(), C.c_int(0)
+    assert ctx.lib.ma_optflow_register(ctx.handle, d.ptr, d.ptr, L.MA_F32, 300, 300, C.byref(prm), flow.ptr, reps, 0,
+                                       C.byref(n)) == L.MA_EINVAL and b"reports buffer" in ctx.lib.ma_last_error()
+    assert ctx.lib.ma_optflow_register(ctx.handle, d.ptr, None, L.MA_F32, 300, 300, C.byref(prm), flow.ptr, None, 0,
+                                       None) == L.MA_EINVAL
+    # reports are optional
+    assert ctx.lib.ma_optflow_register(ctx.handle, d.ptr, d.ptr, L.MA_F32, 300, 300, C.byref(prm), flow.ptr, None, 0,
+                                       None) == L.MA_OK
     reg = make_reg(dict(engine="fortran"))
     reg.ref_img = reg.mov_img = np.ones((300, 300), np.float32)
     with pytest.raises(ValueError, match="unknown engine"):
