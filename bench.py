@@ -117,13 +117,18 @@ def kernel_clocks(workload):
     return out, os.path.relpath(files[-1], ROOT)
 
 
-def valu_flops_per_px(kernel, winsize_taps, fused):
+def valu_flops_per_px(kernel, winsize_taps, fused, iters=3):
     """FP32 lane-operations per processed pixel of the VALU-bound kernels (what a perfect schedule must still issue).
-    Window blurs: 5 planes x (k0 * c, then per tap pair add, multiply, add -- or add, fma).  DOG: two sigmas x (row
-    filter of 41 taps: 41 multiplies + 40 additions; column filter: 1 multiply + 20 x (add, multiply, add)) + the
-    difference + the two normalisations (multiply, add)."""
+    Window blurs: 5 planes x (k0 * c, then per tap pair add, multiply, add -- or add, fma).  The horizontal pass also
+    carries the rest of A.1 steps 3-4 for the pixel: the 2x2 solve (12 operations, f64) in every iteration and, in all
+    but the last, UpdateMatrices (coordinates and weights 8, five bilinear blends 35, the matrix entries 47 = 90).
+    DOG: two sigmas x (row filter of 41 taps: 41 multiplies + 40 additions; column filter: 1 multiply + 20 x (add,
+    multiply, add)) + the difference + the two normalisations (multiply, add)."""
     if kernel in ("blur_v", "blur_h_solve"):
-        return 5 * ((2 if fused else 3) * winsize_taps + 1)
+        fir = 5 * ((2 if fused else 3) * winsize_taps + 1)
+        if kernel == "blur_h_solve":
+            return fir + 12 + 90 * (iters - 1) / iters
+        return fir
     if kernel == "dog":
         return 2 * ((41 + 40) + (1 + 20 * 3)) + 1 + 4
     return 0
@@ -155,7 +160,7 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
     if name in VALU_BOUND and (winsize_taps or name == "dog"):
         # these kernels are bound by FP32 vector issue, not by HBM: price them against the VALU peak at the clock the
         # chip sustains under this instruction mix (ma_clock_probe, same run); the HBM view stays in `hbm`
-        fpp = valu_flops_per_px(name, winsize_taps, fused)
+        fpp = valu_flops_per_px(name, winsize_taps, fused, iters)
         tf = fpp * rec["px"] / sec / 1e12
         # the clock this very kernel held (rocprofv3 summary of the loaded kernels) when there is one, else the probe's
         ghz = kernel_clock or clock_ghz or NOMINAL_GHZ
@@ -167,7 +172,7 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
                     "clock_source": (f"{kernel_clock_source} (GRBM_GUI_ACTIVE of this kernel)" if kernel_clock else
                                      "ma_clock_probe, same run" if clock_ghz else "nominal"),
                     "clock_probe_ghz": round(clock_ghz, 3) if clock_ghz else None,
-                    "flops_per_px": fpp, "arithmetic": "fma" if fused else "mul+add (3 ops per tap pair)", "hbm": hbm})
+                    "flops_per_px": round(fpp, 1), "arithmetic": "fma" if fused else "mul+add (3 ops per tap pair)", "hbm": hbm})
     return out
 
 
