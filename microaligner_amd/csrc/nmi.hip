@@ -199,6 +199,7 @@ int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t 
     MA_TRY(ma_pinned_reserve(ctx, nchunks * sizeof(double)));
     MA_TRY(ma_nmi_u8_enqueue(ctx, a, b, n, chunk, (double*)ctx->pinned, max_scores, n_scores));
     MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->profile) MA_TRY(ma_profile_flush(ctx));   // the stream is idle: recycle the accounting events
     for (int i = 0; i < *n_scores; i++) scores_host[i] = ((double*)ctx->pinned)[i];
     return MA_OK;
 }

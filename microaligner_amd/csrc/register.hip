@@ -284,6 +284,9 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
                                      (int)max_chunks, &n_before));
         }
         MA_HIP(hipStreamSynchronize(ctx->stream));   // the one host round trip of the level
+        // the stream is idle: settle the per-kernel accounting now, so that its events are reused level after level
+        // (a profiled run that only ever creates events stalls for ~0.2 s once the runtime's signal pool has to grow)
+        if (ctx->profile) MA_TRY(ma_profile_flush(ctx));
         const double after = n_after == 1 ? sc_after[0] : ma_np_mean(sc_after, n_after);
         const double before = n_before == 1 ? sc_before[0] : ma_np_mean(sc_before, n_before);
         const bool accepted = after > before;
