@@ -43,12 +43,13 @@ def _stale(target, deps):
 
 
 def source_hash():
-    """sha256 (first 16 hex digits) over every kernel source, the internal header, the public header and the compiler
-    flags: ma_version() carries it, the profile summaries under profiles/ record it, and bench.py only quotes PMC
+    """sha256 (first 16 hex digits) over every source file that holds kernels of the measured path, the internal header,
+    the public header and the compiler flags: ma_version() carries it, the profile summaries under profiles/ record it, and bench.py only quotes PMC
     traffic from a summary whose hash is the loaded library's."""
     import hashlib
     h = hashlib.sha256()
-    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+    host_only = {"ma_api.hip", "register.hip", "probe.hip"}   # no kernel of the measured path lives in these
+    for path in [os.path.join(CSRC, s) for s in SOURCES if s not in host_only] + HEADERS:
         h.update(open(path, "rb").read())
     h.update(" ".join(_flags()).encode())
     return h.hexdigest()[:16]
