@@ -7,11 +7,13 @@ this package's own machinery -- FeatureRegistrator, parallel.register_cycle_chai
 normalisation, chained optical-flow registration, the overlapped page-warp driver writing straight into the output
 memory map).
 
-Deliberately small (the control plane is not the product): one file per cycle ("Cycle N": path) or one stack of all
-cycles ("CycleStack": path); images are TIFF when `tifffile` imports (read through TiffFile.series, written to a BigTIFF
+Deliberately small (the control plane is not the product): one file per cycle ("Cycle N": path), one file per channel
+("Cycle N": {channel: path}, the reference's CycleBuilder form) or one (cycles, C, Z, Y, X) .npy stack of all cycles
+("CycleStack": path); images are TIFF when `tifffile` imports (read through TiffFile.series, written to a BigTIFF
 memory map, channel names taken from the OME-XML description when there is one) and `.npy` arrays otherwise or on
 request -- (C, Z, Y, X), (C, Y, X) or (Y, X) per cycle -- so the pipeline runs in images without tifffile too.  Not
-rebuilt: the CycleBuilder input form, OME-XML rewriting, per-plane metadata (ome_meta_processing.py).
+rebuilt: TIFF CycleStack inputs (they need the OME-XML's per-cycle channel layout), OME-XML rewriting, per-plane metadata
+(ome_meta_processing.py).
 """
 import json
 import os
@@ -87,8 +89,15 @@ class PipelineConfig:
         if isinstance(paths, dict) and "CycleStack" in paths:
             self.input_type, self.paths = "CycleStack", {0: Path(paths["CycleStack"])}
         elif isinstance(paths, dict) and paths and all(isinstance(v, dict) for v in paths.values()):
-            raise NotImplementedError("the CycleBuilder input form (one file per channel) is not rebuilt; give one stack "
-                                      "per cycle or a CycleStack")
+            # CycleBuilder (config_reader.py:203-218): "Cycle N": {channel name: path of that channel's (Z, Y, X) stack}
+            self.input_type, self.paths = "CycleBuilder", {}
+            for name, chans in paths.items():
+                if not re.match(r"Cycle \d+", name):
+                    raise ValueError("Cycle names in config file should follow pattern Cycle N")
+                cyc = int(re.search(r"(\d+)", name).group(1))
+                if len(chans) > len(set(chans)):
+                    raise ValueError(f"Channel names are repeated in the Cycle {cyc}: {list(chans)}")
+                self.paths[cyc] = {ch: Path(p) for ch, p in chans.items()}
         else:
             self.input_type, self.paths = "CycleList", {}
             for name, p in (paths.items() if isinstance(paths, dict) else enumerate(paths, 1)):
@@ -186,9 +195,31 @@ def channel_index(names, ref_channel, what):
 def _load_cycles(cfg):
     """[(cycle id, (C, Z, Y, X) array, channel names)] in cycle order."""
     if cfg.input_type == "CycleStack":
-        arr, names = read_stack(cfg.paths[0])
-        raise NotImplementedError("a single stack of all cycles needs the per-cycle channel layout of its OME-XML; give "
-                                  f"one stack per cycle ({cfg.paths[0]} has {arr.shape[0]} channels)")
+        # one file holding every cycle: a (cycles, C, Z, Y, X) .npy array; the TIFF form needs the per-cycle channel
+        # layout of the OME-XML, which is not rebuilt
+        path = cfg.paths[0]
+        if path.suffix.lower() != ".npy":
+            raise NotImplementedError("a TIFF stack of all cycles needs the per-cycle channel layout of its OME-XML, which "
+                                      "is not rebuilt; give one stack per cycle, or a (cycles, C, Z, Y, X) .npy")
+        arr = np.load(path, mmap_mode="r")
+        if arr.ndim != 5:
+            raise ValueError(f"{path}: a CycleStack .npy must be (cycles, C, Z, Y, X), got shape {arr.shape}")
+        names = [str(i) for i in range(arr.shape[1])]
+        return [(k + 1, arr[k], names) for k in range(arr.shape[0])]
+    if cfg.input_type == "CycleBuilder":
+        out = []
+        for cyc, chans in sorted(cfg.paths.items()):
+            planes = []
+            for ch, p in chans.items():
+                a = np.load(p, mmap_mode="r") if p.suffix.lower() == ".npy" else read_stack(p)[0]
+                a = a.reshape((-1,) + a.shape[-2:])          # one channel per file: whatever leads Y, X is Z
+                planes.append(a)
+            zmax = max(pl.shape[0] for pl in planes)
+            stack = np.zeros((len(planes), zmax) + planes[0].shape[1:], planes[0].dtype)
+            for c, pl in enumerate(planes):
+                stack[c, :pl.shape[0]] = pl
+            out.append((cyc, stack, list(chans)))
+        return out
     return [(cyc,) + read_stack(p) for cyc, p in sorted(cfg.paths.items())]
 
 
@@ -292,7 +323,8 @@ def run(config_path, log=print):
     cfg = read_config(config_path)
     cfg.out_dir.mkdir(parents=True, exist_ok=True)
     cycles = _load_cycles(cfg)
-    fmt = cfg.output_format or ("npy" if all(Path(p).suffix.lower() == ".npy" for p in cfg.paths.values()) else "tif")
+    all_paths = [q for p in cfg.paths.values() for q in (p.values() if isinstance(p, dict) else [p])]
+    fmt = cfg.output_format or ("npy" if all(Path(p).suffix.lower() == ".npy" for p in all_paths) else "tif")
     if fmt not in ("tif", "npy"):
         raise ValueError("Output: OutputFormat must be tif or npy")
     outputs = []

@@ -63,8 +63,9 @@ def test_config_schema_and_validation(tmp_path):
             P.read_config(config(tmp_path, paths, RegistrationParameters__OptFlowReg=dict(REG, **{key: val})))
     with pytest.raises(ValueError, match="At least one of the registration methods"):
         P.read_config(config(tmp_path, paths, RegistrationParameters__OptFlowReg=None))
-    with pytest.raises(NotImplementedError, match="CycleBuilder"):
-        P.read_config(config(tmp_path, {"Cycle 1": {"DAPI": "a.tif"}}))
+    cb = P.read_config(config(tmp_path, {"Cycle 1": {"DAPI": "a.npy", "CD3": "b.npy"}, "Cycle 2": {"DAPI": "c.npy"}}))
+    assert cb.input_type == "CycleBuilder" and cb.paths[1] == {"DAPI": P.Path("a.npy"), "CD3": P.Path("b.npy")}
+    assert P.read_config(config(tmp_path, {"CycleStack": "all.npy"})).input_type == "CycleStack"
 
 
 def test_stack_io_and_channel_lookup(tmp_path):
@@ -79,6 +80,17 @@ def test_stack_io_and_channel_lookup(tmp_path):
         P.channel_index(["DAPI"], "CD8", "cycle 2")
     np.save(tmp_path / "b.npy", a[0, 0])
     assert P.read_stack(tmp_path / "b.npy")[0].shape == (1, 1, 4, 5)
+    # the CycleBuilder form (one file per channel) and the single stack of all cycles load into the same structure
+    np.save(tmp_path / "dapi.npy", a[0])
+    np.save(tmp_path / "cd3.npy", a[1, :2])
+    cb = P.read_config(config(tmp_path, {"Cycle 1": {"DAPI": str(tmp_path / "dapi.npy"), "CD3": str(tmp_path / "cd3.npy")}}))
+    (cyc, stack, names), = P._load_cycles(cb)
+    assert cyc == 1 and sorted(names) == ["CD3", "DAPI"] and stack.shape == (2, 3, 4, 5)
+    d, c = names.index("DAPI"), names.index("CD3")
+    assert np.array_equal(stack[d], a[0]) and np.array_equal(stack[c, :2], a[1, :2]) and not stack[c, 2].any()
+    np.save(tmp_path / "all.npy", np.stack([a, a + 1]))
+    cs = P._load_cycles(P.read_config(config(tmp_path, {"CycleStack": str(tmp_path / "all.npy")})))
+    assert [c[0] for c in cs] == [1, 2] and np.array_equal(cs[1][1], a + 1)
     mm, path = P.create_output(tmp_path / "o.tif", (1, 2, 3, 4, 5), np.uint16, "npy")
     mm[0] = a
     mm.flush()
