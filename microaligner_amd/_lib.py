@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libmicroaligner_hip.so")
 MA_U8, MA_U16, MA_F32 = 0, 1, 2
 MA_OK, MA_EINVAL, MA_ENOMEM, MA_EHIP, MA_ENODEV = 0, -1, -2, -3, -4
 MA_FB_MULADD_FUSED = 1
+MA_KNN_AUTO, MA_KNN_EXACT, MA_KNN_FILTERED = 0, 1, 2   # enum ma_knn_mode
 MA_DOG_FUSED_BLUR, MA_DOG_FUSED_SCALE = 1, 2
 MA_FLOW_CELL_REPLICAS = 8
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "ma_dog_u8_ex": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, C.POINTER(_i)]),
     "ma_warp_affine_cv": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _i, _i, _vp]),
     "ma_knn2_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "ma_knn2_l2_ex": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "ma_fast_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ma_daisy_describe": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.POINTER(_d)), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d),
                                _vp, _vp, _i, _vp]),

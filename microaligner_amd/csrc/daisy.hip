@@ -110,6 +110,76 @@ __global__ __launch_bounds__(256) void smooth_axis_kernel(const float* __restric
     dst[(size_t)blockIdx.z * P * P + (size_t)y * P + x] = (float)acc;
 }
 
+// The same filter for radii up to RB with the window of a thread in registers: the plane is read as [A][B] (B contiguous,
+// one thread per b), filtered along A for NY consecutive outputs per thread -- every input row is loaded and converted
+// once for up to NY outputs instead of once per tap -- and written TRANSPOSED, [B][A], each thread NY contiguous floats.
+// Two launches make scipy's two passes: y then x, the second one reading the transposed intermediate and transposing it
+// back.  Per output the arithmetic is that of smooth_axis_kernel, tap for tap: acc = x[0] w[0]; acc += (x[-j] + x[+j]) w[j],
+// j = r .. 1.  Taps beyond r are skipped by a uniform branch, rows beyond the window a thread needs are not loaded.
+struct __attribute__((packed, aligned(4))) f32x4_u { float v[4]; };
+
+template <int RB, int NY>
+__global__ __launch_bounds__(128) void smooth_transposing_kernel(const float* __restrict__ src, int A, int B,
+                                                                 const double* __restrict__ w, int r, float* __restrict__ dst)
+{
+    const int b = blockIdx.x * 128 + threadIdx.x, a0 = blockIdx.y * NY;
+    if (b >= B) return;
+    const float* s = src + (size_t)blockIdx.z * A * B + b;
+    double win[NY + 2 * RB];
+#pragma unroll
+    for (int i = 0; i < NY + 2 * RB; i++) {
+        const int d = i - RB;
+        win[i] = 0.0;
+        if (d >= -r && d < NY + r) win[i] = (double)s[(size_t)d_clamp(a0 + d, 0, A - 1) * B];
+    }
+    double acc[NY];
+    const double w0 = w[0];
+#pragma unroll
+    for (int o = 0; o < NY; o++) acc[o] = __dmul_rn(win[o + RB], w0);
+#pragma unroll
+    for (int j = RB; j >= 1; j--) {
+        if (j <= r) {
+            const double wj = w[j];
+#pragma unroll
+            for (int o = 0; o < NY; o++) acc[o] = __dadd_rn(acc[o], __dmul_rn(__dadd_rn(win[o + RB - j], win[o + RB + j]), wj));
+        }
+    }
+    float* d = dst + (size_t)blockIdx.z * A * B + (size_t)b * A + a0;
+    if (a0 + NY <= A) {
+#pragma unroll
+        for (int o = 0; o < NY; o += 4) {
+            f32x4_u v = {{(float)acc[o], (float)acc[o + 1], (float)acc[o + 2], (float)acc[o + 3]}};
+            *reinterpret_cast<f32x4_u*>(d + o) = v;
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < NY; o++)
+            if (a0 + o < A) d[o] = (float)acc[o];
+    }
+}
+
+// one smoothing pass pair (y, then x) of `planes` planes of P x P: src -> mid (transposed) -> dst
+static void smooth_planes(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r)
+{
+    if (r <= 12) {
+        const dim3 grid((P + 127) / 128, (P + 15) / 16, planes);
+        hipLaunchKernelGGL((smooth_transposing_kernel<12, 16>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
+        hipLaunchKernelGGL((smooth_transposing_kernel<12, 16>), grid, dim3(128), 0, stream, (const float*)mid, P, P, w, r, dst);
+    } else if (r <= 24) {
+        const dim3 grid((P + 127) / 128, (P + 15) / 16, planes);
+        hipLaunchKernelGGL((smooth_transposing_kernel<24, 16>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
+        hipLaunchKernelGGL((smooth_transposing_kernel<24, 16>), grid, dim3(128), 0, stream, (const float*)mid, P, P, w, r, dst);
+    } else if (r <= 40) {
+        const dim3 grid((P + 127) / 128, (P + 7) / 8, planes);
+        hipLaunchKernelGGL((smooth_transposing_kernel<40, 8>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
+        hipLaunchKernelGGL((smooth_transposing_kernel<40, 8>), grid, dim3(128), 0, stream, (const float*)mid, P, P, w, r, dst);
+    } else {   // any radius: a thread per output, every tap from memory
+        const dim3 pgrid((P + 255) / 256, P, planes);
+        hipLaunchKernelGGL((smooth_axis_kernel<false>), pgrid, dim3(256), 0, stream, src, P, w, r, mid);
+        hipLaunchKernelGGL((smooth_axis_kernel<true>), pgrid, dim3(256), 0, stream, (const float*)mid, P, w, r, dst);
+    }
+}
+
 // Daisy.compute: one thread per (keypoint, histogram location); 25 locations x 8 orientation bins = 200 floats.
 // Location 0 samples cube 0 at the keypoint, location 1 + 8 r + j samples cube r at the keypoint + offs[1 + 8 r + j]
 // (float64 offsets computed by the host with numpy); bilinear weights and the blend in float32, left to right.
@@ -372,15 +442,13 @@ int ma_daisy_describe(ma_ctx* ctx, const void* tiles, int dtype, int nt, int P, 
         if (dtype == MA_U8) hipLaunchKernelGGL((daisy_layers_kernel<uint8_t>), grid, dim3(256), 0, ctx->stream, (const uint8_t*)tiles, P, dtab, tmp);
         else hipLaunchKernelGGL((daisy_layers_kernel<float>), grid, dim3(256), 0, ctx->stream, (const float*)tiles, P, dtab, tmp);
     }
-    const dim3 pgrid((P + 255) / 256, P, nt * 8);
     const float* src = tmp;   // the orientation layers; smoothed successively: cube c = G(inc_c) * cube c-1
     for (int c = 0; c < 3; c++) {
         float* dst = cubes + c * cube;
         // scipy filters axis 1 (y) first, then axis 2 (x), each pass rounding to float32.  The intermediate of the two
         // passes lives in the next cube's slot (not yet written) or, for the last cube, in the layer buffer (done with)
         float* mid = c < 2 ? cubes + (c + 1) * cube : tmp;
-        hipLaunchKernelGGL((smooth_axis_kernel<false>), pgrid, dim3(256), 0, ctx->stream, src, P, dtab + woff[c], radii[c], mid);
-        hipLaunchKernelGGL((smooth_axis_kernel<true>), pgrid, dim3(256), 0, ctx->stream, (const float*)mid, P, dtab + woff[c], radii[c], dst);
+        smooth_planes(ctx->stream, src, mid, dst, P, nt * 8, dtab + woff[c], radii[c]);
         src = dst;
     }
     hipLaunchKernelGGL(daisy_sample_kernel, dim3((nkp * 25 + 255) / 256), dim3(256), 0, ctx->stream, (const float*)cubes, cube, P,

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 
 namespace {
 
@@ -25,10 +26,23 @@ __device__ __forceinline__ void top2_push(Top2& b, float d, int i)
 }
 __device__ __forceinline__ bool before(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
 
+// qlist / qcount: when given, the kernel serves the query rows qlist[0 .. *qcount) instead of 0 .. nq (the fallback of
+// the filtered search below: the grid is sized for nq and the blocks beyond the list leave at once)
 __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, const float* __restrict__ t, int nq, int nt,
-                                                   int dim, int* __restrict__ idx, float* __restrict__ dist)
+                                                   int dim, int* __restrict__ idx, float* __restrict__ dist,
+                                                   const int* __restrict__ qlist, const int* __restrict__ qcount,
+                                                   int split_rows, float4* __restrict__ part)
 {
     extern __shared__ float lds[];
+    const int cap = nq;                      // list positions the partial results are laid out for
+    if (qlist) {
+        nq = *qcount;
+        if ((int)blockIdx.x * KN_TQ >= nq) return;
+    }
+    // gridDim.y > 1: this block serves the train rows [tbeg, tend) only and leaves its pair per query in `part`
+    // (knn2_merge_parts folds them): a handful of queries then occupies the whole chip instead of one CU
+    const int tbeg = gridDim.y > 1 ? (int)blockIdx.y * split_rows : 0;
+    const int tend = gridDim.y > 1 ? min(nt, tbeg + split_rows) : nt;
     const int qp = dim + 4;                  // query pitch; dim % 4 == 0 and (qp / 4) odd when dim % 8 == 0
     float* Qs = lds;                         // [KN_TQ][qp]
     float* Ts = lds + KN_TQ * qp;            // [KN_TT][KN_TP]
@@ -37,14 +51,14 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
     for (int e = tid; e < KN_TQ * (dim / 4); e += 256) {
         const int row = e / (dim / 4), k4 = e - row * (dim / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + row < nq) v = reinterpret_cast<const float4*>(q + (size_t)(q0 + row) * dim)[k4];
+        if (q0 + row < nq) v = reinterpret_cast<const float4*>(q + (size_t)(qlist ? qlist[q0 + row] : q0 + row) * dim)[k4];
         *reinterpret_cast<float4*>(Qs + row * qp + 4 * k4) = v;
     }
     Top2 best[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) { best[r].d0 = best[r].d1 = FLT_MAX; best[r].i0 = best[r].i1 = 0x7fffffff; }
 
-    for (int t0 = 0; t0 < nt; t0 += KN_TT) {
+    for (int t0 = tbeg; t0 < tend; t0 += KN_TT) {
         float acc[4][4];
 #pragma unroll
         for (int r = 0; r < 4; r++)
@@ -56,7 +70,7 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
             for (int u = 0; u < 2; u++) {    // 64 rows x 8 float4 = 512 float4, two per thread
                 const int e = tid + 256 * u, row = e >> 3, k4 = e & 7;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t0 + row < nt && k0 + 4 * k4 < dim) v = reinterpret_cast<const float4*>(t + (size_t)(t0 + row) * dim + k0)[k4];
+                if (t0 + row < tend && k0 + 4 * k4 < dim) v = reinterpret_cast<const float4*>(t + (size_t)(t0 + row) * dim + k0)[k4];
                 *reinterpret_cast<float4*>(Ts + row * KN_TP + 4 * k4) = v;
             }
             __syncthreads();
@@ -84,7 +98,7 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const int j = t0 + tx + 16 * c;
-            if (j < nt) {
+            if (j < tend) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) top2_push(best[r], acc[r][c], j);
             }
@@ -111,28 +125,391 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
             if (before(d, i, d0, i0)) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
             else if (before(d, i, d1, i1)) { d1 = d; i1 = i; }
         }
-        idx[(size_t)(q0 + tid) * 2] = i0;
-        idx[(size_t)(q0 + tid) * 2 + 1] = i1;
-        dist[(size_t)(q0 + tid) * 2] = d0;      // squared; the caller takes the root
-        dist[(size_t)(q0 + tid) * 2 + 1] = d1;
+        if (gridDim.y > 1) {
+            part[(size_t)blockIdx.y * cap + q0 + tid] = make_float4(d0, d1, __int_as_float(i0), __int_as_float(i1));
+            return;
+        }
+        const size_t o = (size_t)(qlist ? qlist[q0 + tid] : q0 + tid) * 2;
+        idx[o] = i0;
+        idx[o + 1] = i1;
+        dist[o] = d0;      // squared; the caller takes the root
+        dist[o + 1] = d1;
     }
+}
+
+// the pairs the train splits of knn2_kernel left for list position p -> the pair of query qlist[p]
+__global__ __launch_bounds__(256) void knn2_merge_parts(const float4* __restrict__ part, int cap, int nsplit,
+                                                        const int* __restrict__ qlist, const int* __restrict__ qcount,
+                                                        int* __restrict__ idx, float* __restrict__ dist)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= *qcount) return;
+    float d0 = FLT_MAX, d1 = FLT_MAX;
+    int i0 = 0x7fffffff, i1 = 0x7fffffff;
+    for (int s = 0; s < nsplit; s++) {
+        const float4 v = part[(size_t)s * cap + p];
+        const float d[2] = {v.x, v.y};
+        const int i[2] = {__float_as_int(v.z), __float_as_int(v.w)};
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            if (i[e] == 0x7fffffff) continue;
+            if (before(d[e], i[e], d0, i0)) { d1 = d0; i1 = i0; d0 = d[e]; i0 = i[e]; }
+            else if (before(d[e], i[e], d1, i1)) { d1 = d[e]; i1 = i[e]; }
+        }
+    }
+    const size_t o = (size_t)qlist[p] * 2;
+    idx[o] = i0;
+    idx[o + 1] = i1;
+    dist[o] = d0;
+    dist[o + 1] = d1;
+}
+
+// ---- filtered search: FP32 MFMA shortlist, exact re-evaluation, certificate, exact fallback --------------------------
+// The result of ma_knn2_l2 is DEFINED by knn2_kernel above (sequential float32 sums of (q - t)^2, ties to the lower
+// index).  For big sets the same result comes cheaper: (1) km_shortlist ranks every train row of a split by
+// a_j = |t_j|^2 - 2 q.t_j, the dot product on v_mfma_f32_32x32x2_f32 (an exact k-ordered fmaf chain), and keeps the four
+// smallest per query and split; (2) km_refine evaluates the defining sum for those 4 S candidates and takes the two
+// smallest; (3) a rigorous rounding bound turns the fourth-smallest a_j of every split into a lower bound on the defining
+// sum of every row that is NOT a candidate -- if the exact second distance is strictly below it, no such row can enter or
+// tie and the pair is final; (4) the few queries without a certificate (near-ties, duplicated descriptors) go through
+// knn2_kernel.  Bit-identical to the exact search by construction, not by tolerance.
+typedef float km_f16 __attribute__((ext_vector_type(16)));
+constexpr int KM_NQ = 128, KM_NT = 128, KM_KC = 40, KM_TP = KM_KC + 4, KM_K = 4, KM_THREADS = 512;
+constexpr int KM_MAX_DIM = 216;                 // Q tile (128 x (dim + 4) floats) + two T chunks + norms within 160 KB
+constexpr int KM_CPR = KM_KC / 4;               // float4 per staged train row and chunk
+
+__global__ __launch_bounds__(256) void km_norms(const float* __restrict__ t, int nt, int dim, float* __restrict__ nt2,
+                                                unsigned* __restrict__ tmax_bits)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    if (j < nt) {
+        const float4* r = reinterpret_cast<const float4*>(t + (size_t)j * dim);
+        for (int k = 0; k < dim / 4; k++) {
+            const float4 v = r[k];
+            s = __builtin_fmaf(v.x, v.x, s); s = __builtin_fmaf(v.y, v.y, s);
+            s = __builtin_fmaf(v.z, v.z, s); s = __builtin_fmaf(v.w, v.w, s);
+        }
+        nt2[j] = s;
+    }
+    // non-negative floats order like their bit patterns
+    float m = s;
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(tmax_bits, __float_as_uint(m));
+}
+
+struct Top4 { float d[KM_K]; int i[KM_K]; };
+
+__device__ __forceinline__ void top4_push(Top4& b, float v, int j)
+{
+    // sorted ascending; the order among equal approximate values does not matter (candidates are re-evaluated)
+    const bool c0 = v < b.d[0], c1 = v < b.d[1], c2 = v < b.d[2];
+    b.d[3] = c2 ? b.d[2] : v;          b.i[3] = c2 ? b.i[2] : j;
+    b.d[2] = c1 ? b.d[1] : (c2 ? v : b.d[2]); b.i[2] = c1 ? b.i[1] : (c2 ? j : b.i[2]);
+    b.d[1] = c0 ? b.d[0] : (c1 ? v : b.d[1]); b.i[1] = c0 ? b.i[0] : (c1 ? j : b.i[1]);
+    b.d[0] = c0 ? v : b.d[0];          b.i[0] = c0 ? j : b.i[0];
+}
+
+// grid (query tiles, splits); 8 waves: wave w ranks the train rows 32 (w & 3) .. + 32 of every 128-row tile against the
+// queries 64 (w >> 2) .. + 64 (two 32 x 32 accumulator tiles: train rows down the registers, one query per lane).
+// The k index is permuted inside groups of 8 (lane half h takes k = 8 g + 4 h + s in step s) identically for both
+// operands: one 16-byte LDS read per operand tile feeds four MFMAs.
+__global__ __launch_bounds__(KM_THREADS) void km_shortlist(const float* __restrict__ q, const float* __restrict__ t,
+                                                           const float* __restrict__ nt2, int nq, int nt, int dim,
+                                                           int tiles_per_split, int* __restrict__ cand_idx,
+                                                           float* __restrict__ cand_a4)
+{
+    extern __shared__ float lds[];
+    const int dimp = (dim + 7) & ~7, qp = dimp + 4;
+    float* Qs = lds;                                   // [KM_NQ][qp]
+    float* Ts = Qs + KM_NQ * qp;                       // [2][KM_NT][KM_TP]
+    float* Ns = Ts + 2 * KM_NT * KM_TP;                // [2][KM_NT]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 3, wn = w >> 2, lr = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * KM_NQ, split = blockIdx.y;
+    const int tile0 = split * tiles_per_split, ntiles_all = (nt + KM_NT - 1) / KM_NT;
+    const int ntiles = min(tiles_per_split, ntiles_all - tile0);
+    const int cpt = (dimp + KM_KC - 1) / KM_KC;        // chunks per train tile
+    const int nchunks = ntiles * cpt;
+
+    for (int e = tid; e < KM_NQ * (qp / 4); e += KM_THREADS) {
+        const int row = e / (qp / 4), k4 = e - row * (qp / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + row < nq && 4 * k4 < dim) v = reinterpret_cast<const float4*>(q + (size_t)(q0 + row) * dim)[k4];
+        *reinterpret_cast<float4*>(Qs + row * qp + 4 * k4) = v;
+    }
+
+    float4 stage[3];
+    float nstage = 0.f;
+    auto fetch = [&](int c) {          // chunk c of the block's sequence -> registers
+        const int tile = tile0 + c / cpt, k0 = (c % cpt) * KM_KC, t0 = tile * KM_NT;
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int e = tid + KM_THREADS * u, row = e / KM_CPR, c4 = e - row * KM_CPR;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < KM_NT * KM_CPR && t0 + row < nt && k0 + 4 * c4 < dim)
+                v = reinterpret_cast<const float4*>(t + (size_t)(t0 + row) * dim + k0)[c4];
+            stage[u] = v;
+        }
+        if (c % cpt == 0 && tid < KM_NT) nstage = t0 + tid < nt ? nt2[t0 + tid] : INFINITY;   // rows past the end rank last
+    };
+    auto commit = [&](int c) {
+        float* dst = Ts + (c & 1) * KM_NT * KM_TP;
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int e = tid + KM_THREADS * u, row = e / KM_CPR, c4 = e - row * KM_CPR;
+            if (e < KM_NT * KM_CPR) *reinterpret_cast<float4*>(dst + row * KM_TP + 4 * c4) = stage[u];
+        }
+        if (c % cpt == 0 && tid < KM_NT) Ns[((c / cpt) & 1) * KM_NT + tid] = nstage;
+    };
+
+    Top4 best[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int e = 0; e < KM_K; e++) { best[n].d[e] = INFINITY; best[n].i[e] = 0x7fffffff; }
+
+    if (nchunks > 0) { fetch(0); commit(0); }
+    __syncthreads();
+    km_f16 acc[2];
+    for (int c = 0; c < nchunks; c++) {
+        const int kc = c % cpt, k0 = kc * KM_KC;
+        if (c + 1 < nchunks) fetch(c + 1);
+        if (kc == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        }
+        const float* Tc = Ts + (c & 1) * KM_NT * KM_TP + (32 * wm + lr) * KM_TP + 4 * lh;
+        const float* Qc = Qs + (64 * wn + lr) * qp + k0 + 4 * lh;
+        const int groups = min(KM_KC, dimp - k0) / 8;
+#pragma unroll
+        for (int g = 0; g < KM_KC / 8; g++) {
+            if (g < groups) {
+                const float4 a = *reinterpret_cast<const float4*>(Tc + 8 * g);
+                const float4 b0 = *reinterpret_cast<const float4*>(Qc + 8 * g);
+                const float4 b1 = *reinterpret_cast<const float4*>(Qc + 32 * qp + 8 * g);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+            }
+        }
+        if (kc == cpt - 1) {
+            // a_j = |t_j|^2 - 2 q.t_j for the 16 train rows this lane holds of either query
+            const int tile = c / cpt, t0 = (tile0 + tile) * KM_NT + 32 * wm + 4 * lh;
+            const float* nrm = Ns + (tile & 1) * KM_NT + 32 * wm + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                const float n2 = nrm[row];
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    const float v = __builtin_fmaf(-2.f, acc[n][r], n2);
+                    if (v < best[n].d[KM_K - 1]) top4_push(best[n], v, t0 + row);
+                }
+            }
+        }
+        if (c + 1 < nchunks) commit(c + 1);
+        __syncthreads();
+    }
+
+    // the eight partial lists of every query (four row groups x two lane halves) -> its four smallest
+    float* cd = Ts;                                            // [KM_NQ][8][KM_K]
+    int* ci = reinterpret_cast<int*>(Ts + KM_NQ * 8 * KM_K);
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int e = 0; e < KM_K; e++) {
+            const int o = ((64 * wn + 32 * n + lr) * 8 + wm * 2 + lh) * KM_K + e;
+            cd[o] = best[n].d[e];
+            ci[o] = best[n].i[e];
+        }
+    __syncthreads();
+    if (tid < KM_NQ && q0 + tid < nq) {
+        Top4 m;
+#pragma unroll
+        for (int e = 0; e < KM_K; e++) { m.d[e] = INFINITY; m.i[e] = 0x7fffffff; }
+        for (int e = 0; e < 8 * KM_K; e++) {
+            const float v = cd[tid * 8 * KM_K + e];
+            if (v < m.d[KM_K - 1]) top4_push(m, v, ci[tid * 8 * KM_K + e]);
+        }
+        const size_t o = (size_t)split * nq + q0 + tid;
+#pragma unroll
+        for (int e = 0; e < KM_K; e++) cand_idx[o * KM_K + e] = m.i[e];
+        cand_a4[o] = m.d[KM_K - 1];     // every row of the split that is not listed ranks at or above this
+    }
+}
+
+// One thread per (query, candidate): the defining sum; then per query the two smallest by (distance, index) and the
+// certificate.  sc = candidates per query rounded up to a power of two (<= 32), 256 / sc queries per block.
+__global__ __launch_bounds__(256) void km_refine(const float* __restrict__ q, const float* __restrict__ t, int nq, int dim,
+                                                 int nsplit, int sc, const int* __restrict__ cand_idx,
+                                                 const float* __restrict__ cand_a4, const unsigned* __restrict__ tmax_bits,
+                                                 int* __restrict__ idx, float* __restrict__ dist, int* __restrict__ qlist,
+                                                 int* __restrict__ qcount)
+{
+    __shared__ float sd[256];
+    __shared__ int si[256];
+    const int tid = threadIdx.x, qpb = 256 / sc, ql = tid / sc, c = tid - ql * sc;
+    const int qi = blockIdx.x * qpb + ql;
+    float d2 = INFINITY, qn = 0.f;
+    int j = 0x7fffffff;
+    if (qi < nq && c < nsplit * KM_K) {
+        const int s = c / KM_K, e = c - s * KM_K;
+        j = cand_idx[((size_t)s * nq + qi) * KM_K + e];
+        if (j != 0x7fffffff) {
+            const float4* qr = reinterpret_cast<const float4*>(q + (size_t)qi * dim);
+            const float4* tr = reinterpret_cast<const float4*>(t + (size_t)j * dim);
+            float a = 0.f;
+            for (int k = 0; k < dim / 4; k++) {
+                const float4 x = qr[k], y = tr[k];
+                float d;
+                d = x.x - y.x; a = a + d * d;
+                d = x.y - y.y; a = a + d * d;
+                d = x.z - y.z; a = a + d * d;
+                d = x.w - y.w; a = a + d * d;
+            }
+            d2 = a;
+        }
+    }
+    sd[tid] = d2;
+    si[tid] = j;
+    __syncthreads();
+    if (c != 0 || qi >= nq) return;
+    float d0 = INFINITY, d1 = INFINITY;
+    int i0 = 0x7fffffff, i1 = 0x7fffffff;
+    for (int e = 0; e < sc; e++) {
+        const float d = sd[tid + e];
+        const int i = si[tid + e];
+        if (i == 0x7fffffff) continue;
+        if (before(d, i, d0, i0)) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
+        else if (before(d, i, d1, i1)) { d1 = d; i1 = i; }
+    }
+    // certificate, in double.  u = 2^-24.  a_j differs from T_j = |t_j|^2 - 2 q.t_j by at most
+    // g (|t_j|^2 + 2 |q| |t_j|), g = (dim + 4) u (two fmaf chains of dim terms and one more rounding); the defining sum
+    // s_j is at least (T_j + |q|^2) (1 - (dim + 3) u) (a sum of non-negative terms, three roundings per term and one
+    // per addition).  Norms enter through their computed values, inflated by their own bound.
+    {
+        const float4* qr = reinterpret_cast<const float4*>(q + (size_t)qi * dim);
+        for (int k = 0; k < dim / 4; k++) {
+            const float4 x = qr[k];
+            qn = __builtin_fmaf(x.x, x.x, qn); qn = __builtin_fmaf(x.y, x.y, qn);
+            qn = __builtin_fmaf(x.z, x.z, qn); qn = __builtin_fmaf(x.w, x.w, qn);
+        }
+    }
+    float a4 = INFINITY;
+    for (int s = 0; s < nsplit; s++) a4 = fminf(a4, cand_a4[(size_t)s * nq + qi]);
+    const double u = 5.9604644775390625e-8, g = (dim + 4) * u * 1.01, dl = (dim + 3) * u * 1.01;
+    const double tm = (double)__uint_as_float(*tmax_bits) * (1.0 + 2.0 * g), qq = (double)qn;
+    const double err = g * (tm + 2.0 * sqrt(qq * (1.0 + 2.0 * g) * tm)) * 1.001;
+    const double lower = ((double)a4 - err + qq * (1.0 - 2.0 * g)) * (1.0 - dl);
+    const bool certified = (double)d1 < lower;      // strictly: a tie would have to be broken by index
+    idx[(size_t)qi * 2] = i0;
+    idx[(size_t)qi * 2 + 1] = i1;
+    dist[(size_t)qi * 2] = d0;
+    dist[(size_t)qi * 2 + 1] = d1;
+    if (!certified) qlist[atomicAdd(qcount, 1)] = qi;
 }
 
 } // namespace
 
-extern "C" int ma_knn2_l2(ma_ctx* ctx, const float* query, int nq, const float* train, int nt, int dim, int* idx_out,
-                          float* dist_out)
+// qlist == nullptr: every query, one block per 64 of them over the whole train set.  With a list (the uncertified
+// queries of the filtered search, few) the train set is cut into `nsplit` ranges served by separate blocks, so that the
+// list costs microseconds instead of one block's pass over every train row; part: nsplit x nq float4 of scratch.
+static int knn2_exact(ma_ctx* ctx, const float* query, int nq, const float* train, int nt, int dim, int* idx_out,
+                      float* dist_out, const int* qlist, const int* qcount, int nsplit, float4* part)
+{
+    size_t lds = (size_t)(KN_TQ * (dim + 4) + KN_TT * KN_TP) * sizeof(float);
+    lds = std::max(lds, (size_t)KN_TQ * 16 * 4 * sizeof(float));   // the final merge reuses the buffer
+    MA_REQUIRE(lds <= 160 * 1024, "descriptor length out of range");
+    if (lds > 64 * 1024)
+        MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MaProfScope ps(ctx, MA_K_OTHER, (double)nq);
+    const int split_rows = nsplit > 1 ? ((nt + nsplit - 1) / nsplit + KN_TT - 1) / KN_TT * KN_TT : nt;
+    if (nsplit > 1) nsplit = (nt + split_rows - 1) / split_rows;
+    hipLaunchKernelGGL(knn2_kernel, dim3((nq + KN_TQ - 1) / KN_TQ, nsplit), dim3(256), lds, ctx->stream, query, train, nq, nt,
+                       dim, idx_out, dist_out, qlist, qcount, split_rows, part);
+    if (nsplit > 1)
+        hipLaunchKernelGGL(knn2_merge_parts, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, part, nq, nsplit, qlist, qcount,
+                           idx_out, dist_out);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const float* train, int nt, int dim, int* idx_out,
+                             float* dist_out, int mode, int* uncertified_host)
 {
     MA_REQUIRE(ctx && query && train && idx_out && dist_out, "NULL argument");
     MA_REQUIRE(nq >= 1 && nt >= 2, "need at least one query and two train descriptors");
     MA_REQUIRE(dim >= 4 && dim % 4 == 0, "the descriptor length must be a multiple of 4 (pad with zeros)");
-    size_t lds = (size_t)(KN_TQ * (dim + 4) + KN_TT * KN_TP) * sizeof(float);
-    lds = std::max(lds, (size_t)KN_TQ * 16 * 4 * sizeof(float));   // the final merge reuses the buffer
-    MA_REQUIRE(lds <= 160 * 1024, "descriptor length out of range");
+    MA_REQUIRE(mode == MA_KNN_AUTO || mode == MA_KNN_EXACT || mode == MA_KNN_FILTERED, "unknown search mode");
+    MA_REQUIRE(mode != MA_KNN_FILTERED || dim <= KM_MAX_DIM, "the filtered search holds descriptors of up to 216 floats");
     MA_HIP(hipSetDevice(ctx->device));
-    MaProfScope ps(ctx, MA_K_OTHER, (double)nq);
-    hipLaunchKernelGGL(knn2_kernel, dim3((nq + KN_TQ - 1) / KN_TQ), dim3(256), lds, ctx->stream, query, train, nq, nt, dim,
-                       idx_out, dist_out);
-    MA_HIP(hipGetLastError());
-    return MA_OK;
+    if (uncertified_host) *uncertified_host = 0;
+    // the shortlist pays once the distance matrix is big; below that the exact kernel is already launch-bound
+    const bool filtered = mode == MA_KNN_FILTERED ||
+                          (mode == MA_KNN_AUTO && dim <= KM_MAX_DIM && nt >= 4 * KM_NT && (double)nq * nt >= 4e6);
+    if (!filtered) return knn2_exact(ctx, query, nq, train, nt, dim, idx_out, dist_out, nullptr, nullptr, 1, nullptr);
+
+    // splits of the train set: enough blocks to fill 256 CUs in whole rounds, every split at least one 128-row tile
+    const int nqt = (nq + KM_NQ - 1) / KM_NQ, ntiles = (nt + KM_NT - 1) / KM_NT;
+    int nsplit = 1;
+    double best = 0.0;
+    for (int s = 1; s <= std::min(8, ntiles); s++) {
+        const double blocks = (double)nqt * s, eff = blocks / (256.0 * std::ceil(blocks / 256.0));
+        if (eff > best + 0.02) { best = eff; nsplit = s; }
+    }
+    const int tiles_per_split = (ntiles + nsplit - 1) / nsplit;
+    nsplit = (ntiles + tiles_per_split - 1) / tiles_per_split;
+    int sc = 4;
+    while (sc < nsplit * KM_K) sc *= 2;
+
+    const int fsplit = std::max(1, std::min(64, nt / 256));      // train ranges of the exact fallback
+    const size_t b_nt2 = ma_align_up((size_t)nt * 4, 256), b_ci = ma_align_up((size_t)nsplit * nq * KM_K * 4, 256),
+                 b_a4 = ma_align_up((size_t)nsplit * nq * 4, 256), b_ql = ma_align_up((size_t)nq * 4, 256),
+                 b_part = fsplit > 1 ? (size_t)fsplit * nq * sizeof(float4) : 0;
+    char* ws = static_cast<char*>(ma_pool_alloc(ctx, b_nt2 + b_ci + b_a4 + b_ql + 256 + b_part));
+    if (!ws) return MA_ENOMEM;
+    float* nt2 = reinterpret_cast<float*>(ws);
+    int* cand_idx = reinterpret_cast<int*>(ws + b_nt2);
+    float* cand_a4 = reinterpret_cast<float*>(ws + b_nt2 + b_ci);
+    int* qlist = reinterpret_cast<int*>(ws + b_nt2 + b_ci + b_a4);
+    unsigned* tmax = reinterpret_cast<unsigned*>(ws + b_nt2 + b_ci + b_a4 + b_ql);
+    int* qcount = reinterpret_cast<int*>(tmax + 1);
+    float4* part = b_part ? reinterpret_cast<float4*>(ws + b_nt2 + b_ci + b_a4 + b_ql + 256) : nullptr;
+    int rc = MA_OK;
+    do {
+        if (hipMemsetAsync(tmax, 0, 8, ctx->stream) != hipSuccess) { rc = MA_EHIP; break; }
+        {
+            MaProfScope ps(ctx, MA_K_OTHER, (double)nq);
+            hipLaunchKernelGGL(km_norms, dim3((nt + 255) / 256), dim3(256), 0, ctx->stream, train, nt, dim, nt2, tmax);
+            const int dimp = (dim + 7) & ~7;
+            const size_t lds = (size_t)(KM_NQ * (dimp + 4) + 2 * KM_NT * KM_TP + 2 * KM_NT) * sizeof(float);
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(km_shortlist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) { rc = MA_EHIP; break; }
+            hipLaunchKernelGGL(km_shortlist, dim3(nqt, nsplit), dim3(KM_THREADS), lds, ctx->stream, query, train, nt2, nq, nt,
+                               dim, tiles_per_split, cand_idx, cand_a4);
+            hipLaunchKernelGGL(km_refine, dim3((nq + 256 / sc - 1) / (256 / sc)), dim3(256), 0, ctx->stream, query, train, nq,
+                               dim, nsplit, sc, cand_idx, cand_a4, tmax, idx_out, dist_out, qlist, qcount);
+            if (hipGetLastError() != hipSuccess) { rc = MA_EHIP; break; }
+        }
+        rc = knn2_exact(ctx, query, nq, train, nt, dim, idx_out, dist_out, qlist, qcount, fsplit, part);
+        if (rc != MA_OK) break;
+        if (uncertified_host) {
+            if (hipMemcpyAsync(uncertified_host, qcount, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = MA_EHIP; break; }
+        }
+    } while (0);
+    if (rc == MA_EHIP) ma_set_error("ma_knn2_l2: %s", hipGetErrorString(hipGetLastError()));
+    ma_pool_free(ctx, ws);
+    return rc;
+}
+
+extern "C" int ma_knn2_l2(ma_ctx* ctx, const float* query, int nq, const float* train, int nt, int dim, int* idx_out,
+                          float* dist_out)
+{
+    return ma_knn2_l2_ex(ctx, query, nq, train, nt, dim, idx_out, dist_out, MA_KNN_AUTO, nullptr);
 }

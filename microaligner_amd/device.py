@@ -604,10 +604,15 @@ class Context:
         self._run(self.lib.ma_warp_affine_cv, img.ptr, _dt(img.dtype), h, w, mm, dh, dw, out.ptr)
         return out
 
-    def knn2(self, query, train):
+    def knn2(self, query, train, mode="auto", stats=None):
         """Exact 2-NN (L2) of every row of `query` among the rows of `train`: (idx (n, 2) int64, dist (n, 2) float32)
         on the host, like feature_reg.sparse_cpu.knn2.  Either side may be a host array or a DeviceArray (descriptors
-        that ma_daisy_describe left on the device are searched where they are)."""
+        that ma_daisy_describe left on the device are searched where they are).
+        mode: "auto" | "exact" | "filtered" (ma_knn2_l2_ex: matrix-core shortlist + exact re-evaluation + certificate;
+        the same result bit for bit); stats: a dict that receives {"uncertified": queries served by the exact fallback}."""
+        modes = {"auto": L.MA_KNN_AUTO, "exact": L.MA_KNN_EXACT, "filtered": L.MA_KNN_FILTERED}
+        if mode not in modes:
+            raise ValueError(f"unknown search mode {mode!r}: auto, exact or filtered")
         def prep(a):
             if isinstance(a, DeviceArray):
                 if a.ndim != 2 or a.dtype != np.float32 or a.shape[1] % 4:
@@ -624,7 +629,11 @@ class Context:
         nq = dq.shape[0]
         # (the image dtypes of asdevice() do not include int32: raw buffers for the results)
         idx, dist = self.empty((nq, 2), np.float32), self.empty((nq, 2), np.float32)
-        self._run(self.lib.ma_knn2_l2, dq.ptr, nq, dt.ptr, dt.shape[0], dq.shape[1], idx.ptr, dist.ptr)
+        unc = C.c_int(0)
+        self._run(self.lib.ma_knn2_l2_ex, dq.ptr, nq, dt.ptr, dt.shape[0], dq.shape[1], idx.ptr, dist.ptr, modes[mode],
+                  C.byref(unc) if stats is not None else None)
+        if stats is not None:
+            stats["uncertified"] = unc.value
         out_i = np.empty((nq, 2), np.int32)
         L.check(self.lib.ma_memcpy_d2h(self.handle, out_i.ctypes.data, idx.ptr, out_i.nbytes))
         return out_i.astype(np.int64), np.sqrt(dist.numpy())   # the kernel returns squared distances

@@ -295,6 +295,82 @@ def test_device_knn2_is_the_exact_search(ctx, nq, nt, dim):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("radius,P", [(9, 173), (21, 173), (21, 330), (36, 140), (60, 173)])
+def test_device_daisy_smoothing_radii(ctx, radius, P):
+    """ma_daisy_describe over the radius buckets of its smoothing kernels (register windows of 12, 24 and 40 taps a side,
+    the tap-by-tap kernel beyond) and over window sizes that are no multiple of the 16 outputs a thread makes: descriptors
+    identical to the oracle's scipy chain at points all over the tile, edges and corners included."""
+    from oracle import feature_oracle as FO
+    from microaligner_amd.feature_reg import feature_detection as FD
+    from microaligner_amd.feature_reg.sparse_cpu import Daisy
+    rng = np.random.default_rng(radius + P)
+    tiles = np.stack([O.dog(synthetic.make_cells(P, P, seed=radius + k), True) for k in range(2)])
+    pts = np.concatenate([rng.integers(0, P, (300, 2)), [[0, 0], [P - 1, P - 1], [0, P - 1], [P - 1, 0], [P // 2, 0]]]).astype(np.float64)
+    halves, cos_sin, offsets = FD._daisy_tables(Daisy(radius=radius, q_radius=3, q_theta=8, q_hist=8))
+    kp_tile = np.repeat(np.arange(2, dtype=np.int32), len(pts))
+    got = ctx.daisy_describe(ctx.asdevice(np.ascontiguousarray(tiles)), kp_tile, np.concatenate([pts, pts]), halves, cos_sin, offsets)
+    for k in range(2):
+        assert np.array_equal(got[k * len(pts):(k + 1) * len(pts)], FO.daisy_describe(tiles[k], pts, radius=radius))
+
+
+def _knn_case(kind, nq, nt, dim, seed):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.random((nq, dim)).astype(np.float32), rng.random((nt, dim)).astype(np.float32)
+    if kind == "histograms":       # DAISY-like: non-negative, unit L2 norm, most of the mass in a few bins
+        def h(n):
+            a = rng.gamma(0.3, 1.0, (n, dim)).astype(np.float32)
+            return a / np.sqrt((a * a).sum(1, keepdims=True), dtype=np.float32)
+        t = h(nt)
+        q = t[rng.integers(0, nt, nq)] + 0.02 * h(nq)      # queries near train rows, as matching descriptors are
+        return q.astype(np.float32), t
+    if kind == "duplicates":       # a few distinct rows, each many times: every query ties among dozens of rows
+        base = rng.random((16, dim)).astype(np.float32)
+        return base[rng.integers(0, 16, nq)], base[rng.integers(0, 16, nt)]
+    if kind == "near_ties":        # rows that differ in the last bits only
+        base = rng.random((1, dim)).astype(np.float32)
+        rows = np.repeat(base, nt, 0)
+        t = np.where(rng.random((nt, dim)) < 0.5, rows, np.nextafter(rows, np.float32(2), dtype=np.float32))
+        return rng.random((nq, dim)).astype(np.float32), t
+    raise KeyError(kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nq,nt,dim", [
+    ("uniform", 1000, 3000, 200), ("uniform", 129, 1000, 200), ("uniform", 1, 2, 200), ("uniform", 300, 5, 8),
+    ("uniform", 257, 131, 216), ("uniform", 64, 700, 12), ("histograms", 2500, 4100, 200), ("duplicates", 500, 1500, 200),
+    ("near_ties", 200, 900, 200), ("uniform", 6000, 9000, 200)])
+def test_filtered_knn2_equals_the_exact_search(ctx, kind, nq, nt, dim):
+    """ma_knn2_l2_ex: the matrix-core shortlist + exact re-evaluation + certificate returns, bit for bit, what the exact
+    kernel returns -- on easy data through the certificate, on ties and duplicates through the exact fallback."""
+    q, t = _knn_case(kind, nq, nt, dim, seed=nq + nt)
+    dq, dt = ctx.asdevice(q), ctx.asdevice(t)
+    stats = {}
+    fi, fd = ctx.knn2(dq, dt, mode="filtered", stats=stats)
+    ei, ed = ctx.knn2(dq, dt, mode="exact")
+    assert np.array_equal(fi, ei) and np.array_equal(fd, ed), (kind, stats)
+    if nq * nt <= 3000 * 5000:
+        si, sd = SP.knn2_sequential(q, t)
+        assert np.array_equal(fi, si) and np.array_equal(fd, sd)
+    if kind in ("uniform", "histograms") and nt > 16:
+        assert stats["uncertified"] <= nq // 50, stats          # the certificate carries the typical case
+    if kind in ("duplicates", "near_ties"):
+        assert stats["uncertified"] > nq // 2, stats            # ... and refuses to guess where rows tie
+    ai, ad = ctx.knn2(dq, dt)                                    # whatever "auto" picks
+    assert np.array_equal(ai, ei) and np.array_equal(ad, ed)
+    with pytest.raises(ValueError):
+        ctx.knn2(dq, dt, mode="fast")
+
+
+@pytest.mark.gpu
+def test_filtered_knn2_limits(ctx):
+    q = np.random.default_rng(0).random((40, 220)).astype(np.float32)
+    ctx.knn2(q, q, mode="auto")                                  # longer descriptors: the exact kernel serves them
+    with pytest.raises(ValueError, match="216"):
+        ctx.knn2(q, q, mode="filtered")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape,tile,seed", [((450, 620), 300, 3), ((700, 700), 1000, 4), ((1300, 1100), 400, 5)])
 def test_device_features_equal_the_host_features(ctx, shape, tile, seed):
     """ma_fast_nms + ma_daisy_describe (all tiles of a level in one batch) against the numpy / scipy code of the
