@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void smooth_axis_kernel(const float* __restric
 // once for up to NY outputs instead of once per tap -- and written TRANSPOSED, [B][A], each thread NY contiguous floats.
 // Two launches make scipy's two passes: y then x, the second one reading the transposed intermediate and transposing it
 // back.  Per output the arithmetic is that of smooth_axis_kernel, tap for tap: acc = x[0] w[0]; acc += (x[-j] + x[+j]) w[j],
-// j = r .. 1.  Taps beyond r are skipped by a uniform branch, rows beyond the window a thread needs are not loaded.
+// j = r .. 1.  Taps beyond r are skipped by a uniform branch (their rows are loaded all the same: clamped addresses).
 struct __attribute__((packed, aligned(4))) f32x4_u { float v[4]; };
 
 template <int RB, int NY>
@@ -125,23 +125,25 @@ __global__ __launch_bounds__(128) void smooth_transposing_kernel(const float* __
     const int b = blockIdx.x * 128 + threadIdx.x, a0 = blockIdx.y * NY;
     if (b >= B) return;
     const float* s = src + (size_t)blockIdx.z * A * B + b;
+    // every row of the window is loaded (clamped addresses are always valid) and every weight read before anything is
+    // used: one batch of loads in flight instead of a round trip per row and per tap
+    float raw[NY + 2 * RB];
+#pragma unroll
+    for (int i = 0; i < NY + 2 * RB; i++) raw[i] = s[(size_t)d_clamp(a0 + i - RB, 0, A - 1) * B];
+    double wv[RB + 1];
+#pragma unroll
+    for (int j = 0; j <= RB; j++) wv[j] = w[j];        // the table is padded: entries beyond r exist and are not used
     double win[NY + 2 * RB];
 #pragma unroll
-    for (int i = 0; i < NY + 2 * RB; i++) {
-        const int d = i - RB;
-        win[i] = 0.0;
-        if (d >= -r && d < NY + r) win[i] = (double)s[(size_t)d_clamp(a0 + d, 0, A - 1) * B];
-    }
+    for (int i = 0; i < NY + 2 * RB; i++) win[i] = (double)raw[i];
     double acc[NY];
-    const double w0 = w[0];
 #pragma unroll
-    for (int o = 0; o < NY; o++) acc[o] = __dmul_rn(win[o + RB], w0);
+    for (int o = 0; o < NY; o++) acc[o] = __dmul_rn(win[o + RB], wv[0]);
 #pragma unroll
     for (int j = RB; j >= 1; j--) {
         if (j <= r) {
-            const double wj = w[j];
 #pragma unroll
-            for (int o = 0; o < NY; o++) acc[o] = __dadd_rn(acc[o], __dmul_rn(__dadd_rn(win[o + RB - j], win[o + RB + j]), wj));
+            for (int o = 0; o < NY; o++) acc[o] = __dadd_rn(acc[o], __dmul_rn(__dadd_rn(win[o + RB - j], win[o + RB + j]), wv[j]));
         }
     }
     float* d = dst + (size_t)blockIdx.z * A * B + (size_t)b * A + a0;
@@ -165,6 +167,10 @@ static void smooth_planes(hipStream_t stream, const float* src, float* mid, floa
         const dim3 grid((P + 127) / 128, (P + 15) / 16, planes);
         hipLaunchKernelGGL((smooth_transposing_kernel<12, 16>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
         hipLaunchKernelGGL((smooth_transposing_kernel<12, 16>), grid, dim3(128), 0, stream, (const float*)mid, P, P, w, r, dst);
+    } else if (r <= 18) {
+        const dim3 grid((P + 127) / 128, (P + 15) / 16, planes);
+        hipLaunchKernelGGL((smooth_transposing_kernel<18, 16>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
+        hipLaunchKernelGGL((smooth_transposing_kernel<18, 16>), grid, dim3(128), 0, stream, (const float*)mid, P, P, w, r, dst);
     } else if (r <= 24) {
         const dim3 grid((P + 127) / 128, (P + 15) / 16, planes);
         hipLaunchKernelGGL((smooth_transposing_kernel<24, 16>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
@@ -225,17 +231,21 @@ __global__ __launch_bounds__(256) void cut_tiles_kernel(const uint8_t* __restric
 
 // ---- keypoint selection on the device ------------------------------------------------------------------------------
 // feature_detection.py:105-106: the corners of a tile sorted by response, strongest first (Python's stable sort keeps
-// the detector's row-major order among equal responses), cut to the per-tile limit.  One block per tile over the
-// non-maximum-suppressed score map:
-//   A. histogram of the scores (1 .. 254) -> the cut-off score s* and how many corners of exactly that score still fit;
-//   B. one ordered pass (row-major chunks, block scans) collects every corner above s* and the first `need_eq` of the
-//      corners at s* into LDS as keys (65535 - score) << 32 | row-major index;
-//   C. bitonic sort of the <= 8192 keys in LDS: ascending key = descending score, row-major among equals.
-constexpr int KS_T = 1024, KS_E = 8, KS_CAP = 8192;
+// the detector's row-major order among equal responses), cut to the per-tile limit.  Over the non-maximum-suppressed
+// score map of every tile, in chunks of 4096 scores (one block each, so that a level of one or four tiles still fills
+// the chip; a single block per tile spent a millisecond walking its map):
+//   A. histogram of the scores (1 .. 254) per chunk and per tile -> the cut-off score s*, how many corners of exactly
+//      that score still fit, and by a scan over the chunk histograms where every chunk's share of the selection starts;
+//   B. every chunk collects its corners above s* and, by rank in row-major order, its share of the first `need_eq`
+//      corners at s* as keys (65535 - score) << 32 | row-major index;
+//   C. bitonic sort of the tile's <= 8192 keys in LDS: ascending key = descending score, row-major among equals.
+constexpr int KS_T = 1024, KS_CAP = 8192;       // sorting block, most keys per tile
+constexpr int KC_T = 256, KC_E = 16, KC_CH = KC_T * KC_E;   // a chunk of the score map: 256 threads x 16 consecutive scores
 
+template <int T>
 __device__ __forceinline__ int ks_block_exscan(int v, int* wsum, int& total)
 {
-    // exclusive scan of one int per thread over the 1024-thread block; total = block sum (all threads)
+    // exclusive scan of one int per thread over a block of T threads; total = block sum (all threads)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int inc = v;
 #pragma unroll
@@ -247,7 +257,7 @@ __device__ __forceinline__ int ks_block_exscan(int v, int* wsum, int& total)
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < KS_T / 64; k++) {
+    for (int k = 0; k < T / 64; k++) {
         const int sk = wsum[k];
         if (k < wv) base += sk;
         tot += sk;
@@ -257,24 +267,36 @@ __device__ __forceinline__ int ks_block_exscan(int v, int* wsum, int& total)
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(KS_T) void kp_select_kernel(const int* __restrict__ score, int Pi, int limit, int* __restrict__ kp_out,
-                                                        int* __restrict__ counts)
+// A. histograms: of every chunk (kept: the cut-off turns them into the chunk's share of the selection) and of the tile
+__global__ __launch_bounds__(KC_T) void kp_chunk_hist_kernel(const int* __restrict__ score, int n, int nch,
+                                                             int* __restrict__ chunk_hist, int* __restrict__ tile_hist)
 {
-    __shared__ unsigned long long keys[KS_CAP];
     __shared__ int hist[256];
-    __shared__ int wsum[KS_T / 64];
-    __shared__ int cut[3];   // s*, need_eq, n_sel
-    const int t = blockIdx.x, tid = threadIdx.x;
-    const int* s = score + (size_t)t * Pi * Pi;
-    const int n = Pi * Pi;
-    for (int i = tid; i < 256; i += KS_T) hist[i] = 0;
+    const int t = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int* s = score + (size_t)t * n;
+    hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += KS_T) {
-        const int v = s[i];
+    const int i0 = c * KC_CH + tid * KC_E;
+#pragma unroll
+    for (int e = 0; e < KC_E; e++) {
+        const int v = i0 + e < n ? s[i0 + e] : 0;
         if (v > 0) atomicAdd(&hist[v < 255 ? v : 255], 1);
     }
     __syncthreads();
+    const int h = hist[tid];
+    chunk_hist[((size_t)t * nch + c) * 256 + tid] = h;
+    if (h && tid) atomicAdd(&tile_hist[t * 256 + tid], h);
+}
+
+// the cut-off score s*, how many corners of exactly that score still fit, and where every chunk's share starts
+__global__ __launch_bounds__(KC_T) void kp_cut_kernel(const int* __restrict__ chunk_hist, const int* __restrict__ tile_hist,
+                                                      int nch, int limit, int* __restrict__ cut, int* __restrict__ chunk_base)
+{
+    __shared__ int wsum[KC_T / 64];
+    __shared__ int sc[3];
+    const int t = blockIdx.x, tid = threadIdx.x;
     if (tid == 0) {
+        const int* hist = tile_hist + t * 256;
         int total = 0;
         for (int k = 1; k < 256; k++) total += hist[k];
         int sstar = 0, need_eq = 0;
@@ -285,42 +307,78 @@ __global__ __launch_bounds__(KS_T) void kp_select_kernel(const int* __restrict__
                 gt += hist[k];
             }
         }
-        cut[0] = sstar; cut[1] = need_eq; cut[2] = total < limit ? total : limit;
+        sc[0] = sstar; sc[1] = need_eq; sc[2] = total < limit ? total : limit;
+        cut[t * 3] = sstar; cut[t * 3 + 1] = need_eq; cut[t * 3 + 2] = sc[2];
     }
     __syncthreads();
-    const int sstar = cut[0], need_eq = cut[1], n_sel = cut[2];
-    int eq_base = 0, sel_base = 0;
-    for (int c0 = 0; c0 < n; c0 += KS_T * KS_E) {
-        const int i0 = c0 + tid * KS_E;
-        int v[KS_E], neq = 0;
-#pragma unroll
-        for (int e = 0; e < KS_E; e++) {
-            v[e] = i0 + e < n ? s[i0 + e] : 0;
-            neq += (sstar > 0 && v[e] == sstar) ? 1 : 0;
+    const int sstar = sc[0], need_eq = sc[1];
+    int eq_run = 0, sel_run = 0;
+    for (int c0 = 0; c0 < nch; c0 += KC_T) {
+        const int c = c0 + tid;
+        int gt = 0, eq = 0;
+        if (c < nch) {
+            const int* h = chunk_hist + ((size_t)t * nch + c) * 256;
+            for (int k = sstar + 1; k < 256; k++) gt += h[k];
+            eq = sstar > 0 ? h[sstar] : 0;
         }
-        int eq_total;
-        int eq_rank = eq_base + ks_block_exscan(neq, wsum, eq_total);
-        int nsel = 0;
-        bool take[KS_E];
-#pragma unroll
-        for (int e = 0; e < KS_E; e++) {
-            bool tk = v[e] > sstar;                              // sstar == 0: every corner
-            if (sstar > 0 && v[e] == sstar) { tk = eq_rank < need_eq; eq_rank++; }
-            take[e] = tk;
-            nsel += tk ? 1 : 0;
+        int eq_tot, sel_tot;
+        const int eq_base = eq_run + ks_block_exscan<KC_T>(eq, wsum, eq_tot);
+        const int take_eq = min(eq, max(need_eq - eq_base, 0));          // the first need_eq of them in row-major order
+        const int sel_base = sel_run + ks_block_exscan<KC_T>(gt + take_eq, wsum, sel_tot);
+        if (c < nch) {
+            chunk_base[((size_t)t * nch + c) * 2] = eq_base;
+            chunk_base[((size_t)t * nch + c) * 2 + 1] = sel_base;
         }
-        int sel_total;
-        int pos = sel_base + ks_block_exscan(nsel, wsum, sel_total);
-#pragma unroll
-        for (int e = 0; e < KS_E; e++)
-            if (take[e]) keys[pos++] = ((unsigned long long)(65535 - v[e]) << 32) | (unsigned)(i0 + e);
-        eq_base += eq_total;
-        sel_base += sel_total;
+        eq_run += eq_tot;
+        sel_run += sel_tot;
     }
-    __syncthreads();
+}
+
+// B. every chunk puts its corners above s* and its share of the corners at s* into the tile's key list as
+//    (65535 - score) << 32 | row-major index (the order of the list does not matter: it is sorted next)
+__global__ __launch_bounds__(KC_T) void kp_collect_kernel(const int* __restrict__ score, int n, int nch,
+                                                          const int* __restrict__ cut, const int* __restrict__ chunk_base,
+                                                          unsigned long long* __restrict__ keys)
+{
+    __shared__ int wsum[KC_T / 64];
+    const int t = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int* s = score + (size_t)t * n;
+    const int sstar = cut[t * 3], need_eq = cut[t * 3 + 1];
+    const int i0 = c * KC_CH + tid * KC_E;
+    int v[KC_E], neq = 0;
+#pragma unroll
+    for (int e = 0; e < KC_E; e++) {
+        v[e] = i0 + e < n ? s[i0 + e] : 0;
+        neq += (sstar > 0 && v[e] == sstar) ? 1 : 0;
+    }
+    int tot;
+    int eq_rank = chunk_base[((size_t)t * nch + c) * 2] + ks_block_exscan<KC_T>(neq, wsum, tot);
+    int nsel = 0;
+    bool take[KC_E];
+#pragma unroll
+    for (int e = 0; e < KC_E; e++) {
+        bool tk = v[e] > sstar;                              // sstar == 0: every corner
+        if (sstar > 0 && v[e] == sstar) { tk = eq_rank < need_eq; eq_rank++; }
+        take[e] = tk;
+        nsel += tk ? 1 : 0;
+    }
+    int pos = chunk_base[((size_t)t * nch + c) * 2 + 1] + ks_block_exscan<KC_T>(nsel, wsum, tot);
+    unsigned long long* k = keys + (size_t)t * KS_CAP;
+#pragma unroll
+    for (int e = 0; e < KC_E; e++)
+        if (take[e]) k[pos++] = ((unsigned long long)(65535 - v[e]) << 32) | (unsigned)(i0 + e);
+}
+
+// C. bitonic sort of the tile's <= 8192 keys in LDS: ascending key = descending score, row-major among equals
+__global__ __launch_bounds__(KS_T) void kp_sort_kernel(const unsigned long long* __restrict__ keys_in, const int* __restrict__ cut,
+                                                       int Pi, int limit, int* __restrict__ kp_out, int* __restrict__ counts)
+{
+    __shared__ unsigned long long keys[KS_CAP];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int n_sel = cut[t * 3 + 2];
     int m = 1;
     while (m < n_sel) m <<= 1;
-    for (int i = n_sel + tid; i < m; i += KS_T) keys[i] = ~0ull;
+    for (int i = tid; i < m; i += KS_T) keys[i] = i < n_sel ? keys_in[(size_t)t * KS_CAP + i] : ~0ull;
     __syncthreads();
     for (int k = 2; k <= m; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -372,18 +430,37 @@ int ma_fast_keypoints(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int marg
     MA_REQUIRE(threshold >= 0 && threshold < 254, "bad threshold");
     MA_HIP(hipSetDevice(ctx->device));
     const int Pi = P - 2 * margin;
-    const size_t map = (size_t)nt * Pi * Pi * sizeof(int);
-    MA_TRY(ma_ws_reserve(ctx, 2 * map + (size_t)nt * sizeof(int)));
+    const size_t npx = (size_t)Pi * Pi, map = (size_t)nt * npx * sizeof(int);
+    const int nch = (int)((npx + KC_CH - 1) / KC_CH);
+    MA_REQUIRE(nch <= 65535 * 32, "tile too large");
+    // workspace: raw scores, suppressed scores, per-chunk histograms, key lists, tile histograms, chunk bases, cuts, counts
+    const size_t b_ch = (size_t)nt * nch * 256 * sizeof(int), b_keys = (size_t)nt * KS_CAP * sizeof(unsigned long long),
+                 b_th = (size_t)nt * 256 * sizeof(int), b_cb = (size_t)nt * nch * 2 * sizeof(int), b_cut = (size_t)nt * 4 * sizeof(int);
+    MA_TRY(ma_ws_reserve(ctx, 2 * map + b_keys + b_ch + b_th + b_cb + b_cut + (size_t)nt * sizeof(int) + 64));
     MA_TRY(ma_pinned_reserve(ctx, (size_t)nt * sizeof(int)));
     int* raw = (int*)ctx->ws;
-    int* nms = raw + (size_t)nt * Pi * Pi;
-    int* counts = nms + (size_t)nt * Pi * Pi;
+    int* nms = raw + (size_t)nt * npx;
+    unsigned long long* keys = (unsigned long long*)((char*)ctx->ws + ma_align_up(2 * map, 8));
+    int* chunk_hist = (int*)(keys + (size_t)nt * KS_CAP);
+    int* tile_hist = chunk_hist + (size_t)nt * nch * 256;
+    int* chunk_base = tile_hist + (size_t)nt * 256;
+    int* cut = chunk_base + (size_t)nt * nch * 2;
+    int* counts = cut + (size_t)nt * 4;
     {
         MaProfScope ps(ctx, MA_K_OTHER, (double)nt * Pi * Pi);
         const dim3 grid((Pi + 255) / 256, Pi, nt);
+        MA_HIP(hipMemsetAsync(tile_hist, 0, b_th, ctx->stream));
         hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, ctx->stream, tiles, P, margin, threshold, raw);
         hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, ctx->stream, (const int*)raw, Pi, nms);
-        hipLaunchKernelGGL(kp_select_kernel, dim3(nt), dim3(KS_T), 0, ctx->stream, (const int*)nms, Pi, limit, kp_out, counts);
+        // selection: chunk histograms -> cut-off and chunk bases -> keys -> sort (one block per tile only for the sort)
+        hipLaunchKernelGGL(kp_chunk_hist_kernel, dim3(nch, nt), dim3(KC_T), 0, ctx->stream, (const int*)nms, (int)npx, nch,
+                           chunk_hist, tile_hist);
+        hipLaunchKernelGGL(kp_cut_kernel, dim3(nt), dim3(KC_T), 0, ctx->stream, (const int*)chunk_hist, (const int*)tile_hist, nch,
+                           limit, cut, chunk_base);
+        hipLaunchKernelGGL(kp_collect_kernel, dim3(nch, nt), dim3(KC_T), 0, ctx->stream, (const int*)nms, (int)npx, nch,
+                           (const int*)cut, (const int*)chunk_base, keys);
+        hipLaunchKernelGGL(kp_sort_kernel, dim3(nt), dim3(KS_T), 0, ctx->stream, (const unsigned long long*)keys, (const int*)cut,
+                           Pi, limit, kp_out, counts);
         MA_HIP(hipGetLastError());
     }
     MA_HIP(hipMemcpyAsync(ctx->pinned, counts, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -418,7 +495,7 @@ int ma_daisy_describe(ma_ctx* ctx, const void* tiles, int dtype, int nt, int P, 
     MA_HIP(hipSetDevice(ctx->device));
     // small tables: 8 (cos, sin) pairs, 25 (dy, dx) offsets, three centre-first half kernels
     const size_t ntab = 16 + 50 + (size_t)(radii[0] + radii[1] + radii[2] + 3);
-    MA_TRY(ma_dconst_reserve(ctx, ntab * sizeof(double)));
+    MA_TRY(ma_dconst_reserve(ctx, (ntab + 64) * sizeof(double)));   // + 64: the smoothing kernels read a whole bucket of weights
     std::vector<double> tab(ntab);
     for (int i = 0; i < 16; i++) tab[i] = cos_sin_host[i];
     for (int i = 0; i < 50; i++) tab[16 + i] = offs_host[i];
