@@ -112,74 +112,77 @@ __global__ __launch_bounds__(256) void smooth_axis_kernel(const float* __restric
 
 // The same filter for radii up to RB with the window of a thread in registers: the plane is read as [A][B] (B contiguous,
 // one thread per b), filtered along A for NY consecutive outputs per thread -- every input row is loaded and converted
-// once for up to NY outputs instead of once per tap -- and written TRANSPOSED, [B][A], each thread NY contiguous floats.
+// once for up to NY outputs instead of once per tap -- and written TRANSPOSED, [B][A], through LDS.
 // Two launches make scipy's two passes: y then x, the second one reading the transposed intermediate and transposing it
 // back.  Per output the arithmetic is that of smooth_axis_kernel, tap for tap: acc = x[0] w[0]; acc += (x[-j] + x[+j]) w[j],
 // j = r .. 1.  Taps beyond r are skipped by a uniform branch (their rows are loaded all the same: clamped addresses).
-struct __attribute__((packed, aligned(4))) f32x4_u { float v[4]; };
+constexpr int ST_B = 64;      // one wave per block: 64 columns b
 
-template <int RB, int NY>
-__global__ __launch_bounds__(128) void smooth_transposing_kernel(const float* __restrict__ src, int A, int B,
-                                                                 const double* __restrict__ w, int r, float* __restrict__ dst)
+template <int RB, int NY, int NIT>
+__global__ __launch_bounds__(ST_B) void smooth_transposing_kernel(const float* __restrict__ src, int A, int B,
+                                                                  const double* __restrict__ w, int r, float* __restrict__ dst)
 {
-    const int b = blockIdx.x * 128 + threadIdx.x, a0 = blockIdx.y * NY;
-    if (b >= B) return;
+    // the wave's outputs, [b][a] with a odd pitch: written a column of NY per thread, read back a row of 64 per store,
+    // so that the transposed plane is written in runs of 256 contiguous bytes and not in pieces of a thread's 64
+    constexpr int NA = NY * NIT, TP = NA + 1;
+    __shared__ float tile[ST_B * TP];
+    const int lane = threadIdx.x, b0 = blockIdx.x * ST_B, a00 = blockIdx.y * NA;
+    const int b = min(b0 + lane, B - 1);         // lanes past the edge compute a copy of the last column and store nothing
     const float* s = src + (size_t)blockIdx.z * A * B + b;
-    // every row of the window is loaded (clamped addresses are always valid) and every weight read before anything is
-    // used: one batch of loads in flight instead of a round trip per row and per tap
-    float raw[NY + 2 * RB];
-#pragma unroll
-    for (int i = 0; i < NY + 2 * RB; i++) raw[i] = s[(size_t)d_clamp(a0 + i - RB, 0, A - 1) * B];
     double wv[RB + 1];
 #pragma unroll
     for (int j = 0; j <= RB; j++) wv[j] = w[j];        // the table is padded: entries beyond r exist and are not used
-    double win[NY + 2 * RB];
+    for (int it = 0; it < NIT; it++) {
+        const int a0 = a00 + it * NY;
+        if (a0 >= A) break;
+        // every row of the window is loaded (clamped addresses are always valid) before anything is used: one batch of
+        // loads in flight instead of a round trip per row
+        float raw[NY + 2 * RB];
 #pragma unroll
-    for (int i = 0; i < NY + 2 * RB; i++) win[i] = (double)raw[i];
-    double acc[NY];
+        for (int i = 0; i < NY + 2 * RB; i++) raw[i] = s[(size_t)d_clamp(a0 + i - RB, 0, A - 1) * B];
+        double win[NY + 2 * RB];
 #pragma unroll
-    for (int o = 0; o < NY; o++) acc[o] = __dmul_rn(win[o + RB], wv[0]);
+        for (int i = 0; i < NY + 2 * RB; i++) win[i] = (double)raw[i];
+        double acc[NY];
 #pragma unroll
-    for (int j = RB; j >= 1; j--) {
-        if (j <= r) {
+        for (int o = 0; o < NY; o++) acc[o] = __dmul_rn(win[o + RB], wv[0]);
 #pragma unroll
-            for (int o = 0; o < NY; o++) acc[o] = __dadd_rn(acc[o], __dmul_rn(__dadd_rn(win[o + RB - j], win[o + RB + j]), wv[j]));
+        for (int j = RB; j >= 1; j--) {
+            if (j <= r) {
+#pragma unroll
+                for (int o = 0; o < NY; o++)
+                    acc[o] = __dadd_rn(acc[o], __dmul_rn(__dadd_rn(win[o + RB - j], win[o + RB + j]), wv[j]));
+            }
         }
+#pragma unroll
+        for (int o = 0; o < NY; o++) tile[lane * TP + it * NY + o] = (float)acc[o];
     }
-    float* d = dst + (size_t)blockIdx.z * A * B + (size_t)b * A + a0;
-    if (a0 + NY <= A) {
-#pragma unroll
-        for (int o = 0; o < NY; o += 4) {
-            f32x4_u v = {{(float)acc[o], (float)acc[o + 1], (float)acc[o + 2], (float)acc[o + 3]}};
-            *reinterpret_cast<f32x4_u*>(d + o) = v;
+    __syncthreads();
+    float* d = dst + (size_t)blockIdx.z * A * B + a00;
+    const int nb = min(ST_B, B - b0);
+    for (int a = lane; a < NA; a += 64) {
+        if (a00 + a < A) {
+            for (int bb = 0; bb < nb; bb++) d[(size_t)(b0 + bb) * A + a] = tile[bb * TP + a];
         }
-    } else {
-#pragma unroll
-        for (int o = 0; o < NY; o++)
-            if (a0 + o < A) d[o] = (float)acc[o];
     }
 }
 
 // one smoothing pass pair (y, then x) of `planes` planes of P x P: src -> mid (transposed) -> dst
+template <int RB, int NY, int NIT>
+static void smooth_pair(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r)
+{
+    const dim3 grid((P + ST_B - 1) / ST_B, (P + NY * NIT - 1) / (NY * NIT), planes);
+    hipLaunchKernelGGL((smooth_transposing_kernel<RB, NY, NIT>), grid, dim3(ST_B), 0, stream, src, P, P, w, r, mid);
+    hipLaunchKernelGGL((smooth_transposing_kernel<RB, NY, NIT>), grid, dim3(ST_B), 0, stream, (const float*)mid, P, P, w, r, dst);
+}
+
 static void smooth_planes(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r)
 {
-    if (r <= 12) {
-        const dim3 grid((P + 127) / 128, (P + 15) / 16, planes);
-        hipLaunchKernelGGL((smooth_transposing_kernel<12, 16>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
-        hipLaunchKernelGGL((smooth_transposing_kernel<12, 16>), grid, dim3(128), 0, stream, (const float*)mid, P, P, w, r, dst);
-    } else if (r <= 18) {
-        const dim3 grid((P + 127) / 128, (P + 15) / 16, planes);
-        hipLaunchKernelGGL((smooth_transposing_kernel<18, 16>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
-        hipLaunchKernelGGL((smooth_transposing_kernel<18, 16>), grid, dim3(128), 0, stream, (const float*)mid, P, P, w, r, dst);
-    } else if (r <= 24) {
-        const dim3 grid((P + 127) / 128, (P + 15) / 16, planes);
-        hipLaunchKernelGGL((smooth_transposing_kernel<24, 16>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
-        hipLaunchKernelGGL((smooth_transposing_kernel<24, 16>), grid, dim3(128), 0, stream, (const float*)mid, P, P, w, r, dst);
-    } else if (r <= 40) {
-        const dim3 grid((P + 127) / 128, (P + 7) / 8, planes);
-        hipLaunchKernelGGL((smooth_transposing_kernel<40, 8>), grid, dim3(128), 0, stream, src, P, P, w, r, mid);
-        hipLaunchKernelGGL((smooth_transposing_kernel<40, 8>), grid, dim3(128), 0, stream, (const float*)mid, P, P, w, r, dst);
-    } else {   // any radius: a thread per output, every tap from memory
+    if (r <= 12) smooth_pair<12, 16, 4>(stream, src, mid, dst, P, planes, w, r);
+    else if (r <= 18) smooth_pair<18, 16, 4>(stream, src, mid, dst, P, planes, w, r);
+    else if (r <= 24) smooth_pair<24, 16, 4>(stream, src, mid, dst, P, planes, w, r);
+    else if (r <= 40) smooth_pair<40, 8, 8>(stream, src, mid, dst, P, planes, w, r);
+    else {   // any radius: a thread per output, every tap from memory
         const dim3 pgrid((P + 255) / 256, P, planes);
         hipLaunchKernelGGL((smooth_axis_kernel<false>), pgrid, dim3(256), 0, stream, src, P, w, r, mid);
         hipLaunchKernelGGL((smooth_axis_kernel<true>), pgrid, dim3(256), 0, stream, (const float*)mid, P, w, r, dst);
