@@ -48,8 +48,10 @@ def source_hash():
     traffic from a summary whose hash is the loaded library's."""
     import hashlib
     h = hashlib.sha256()
-    host_only = {"ma_api.hip", "register.hip", "probe.hip"}   # no kernel of the measured path lives in these
-    for path in [os.path.join(CSRC, s) for s in SOURCES if s not in host_only] + HEADERS:
+    # no kernel of the measured path (cfg3: pyramid, DOG, Farneback, warp, merge, NMI) lives in these: host code, the
+    # clock probe, and the feature stage (FAST / DAISY / 2-NN / affine warp), which has its own tests and timings
+    off_path = {"ma_api.hip", "register.hip", "probe.hip", "knn.hip", "daisy.hip", "affine.hip"}
+    for path in [os.path.join(CSRC, s) for s in SOURCES if s not in off_path] + HEADERS:
         h.update(open(path, "rb").read())
     h.update(" ".join(_flags()).encode())
     return h.hexdigest()[:16]
