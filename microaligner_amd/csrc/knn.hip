@@ -281,21 +281,24 @@ __global__ __launch_bounds__(KM_THREADS) void km_shortlist(const float* __restri
         const float* Tc = Ts + (c & 1) * KM_NT * KM_TP + (32 * wm + lr) * KM_TP + 4 * lh;
         const float* Qc = Qs + (64 * wn + lr) * qp + k0 + 4 * lh;
         const int groups = min(KM_KC, dimp - k0) / 8;
+        auto group = [&](int g) {
+            const float4 a = *reinterpret_cast<const float4*>(Tc + 8 * g);
+            const float4 b0 = *reinterpret_cast<const float4*>(Qc + 8 * g);
+            const float4 b1 = *reinterpret_cast<const float4*>(Qc + 32 * qp + 8 * g);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+        };
+        if (groups == KM_KC / 8) {      // a whole chunk (always, when dim is a multiple of 40): straight-line code
 #pragma unroll
-        for (int g = 0; g < KM_KC / 8; g++) {
-            if (g < groups) {
-                const float4 a = *reinterpret_cast<const float4*>(Tc + 8 * g);
-                const float4 b0 = *reinterpret_cast<const float4*>(Qc + 8 * g);
-                const float4 b1 = *reinterpret_cast<const float4*>(Qc + 32 * qp + 8 * g);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
-            }
+            for (int g = 0; g < KM_KC / 8; g++) group(g);
+        } else {
+            for (int g = 0; g < groups; g++) group(g);
         }
         if (kc == cpt - 1) {
             // a_j = |t_j|^2 - 2 q.t_j for the 16 train rows this lane holds of either query
