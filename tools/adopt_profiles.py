@@ -24,6 +24,11 @@ if traffic.get("kernel_source_hash") != want:
     sys.exit(f"the summaries were collected with kernel sources {traffic.get('kernel_source_hash')}, this tree is {want}")
 for name in (f"{tag}_kernel_stats_cfg3.csv", f"{tag}_hbm_traffic_cfg3.json"):
     shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", name))
+# the GPU box has no .git: the commit the measured tree descends from is recorded here, at adoption
+import subprocess
+head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+traffic["head_when_adopted"] = head
+json.dump(traffic, open(os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic_cfg3.json"), "w"), indent=1)
 if len(sys.argv) > 2:
     clk = {}
     for ln in open(sys.argv[2]):
