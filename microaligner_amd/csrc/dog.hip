@@ -67,9 +67,45 @@ __global__ __launch_bounds__(256) void minmax_partial(const T* __restrict__ src,
     block_minmax_256(lo, hi, part + blockIdx.x * 2);
 }
 
+// scalars of the DOG chain, produced and consumed on the device
+struct DogScalars {
+    float mm_src[2];   // min, max of the input
+    float mm_diff[2];  // min, max of hs - ls
+    float a, b;        // normalize(src, 0, 1, MINMAX, 32F):  v*a + b
+    float a8, b8;      // normalize(diff, 0, 255, MINMAX, 8U): v*a8 + b8
+    int src_max_is_zero;
+};
+
+// normalize(src, 0, 1, NORM_MINMAX, CV_32F): scale rounded to float, shift = (float)0 - (float)(smin*scale)
+__device__ __forceinline__ void d_dog_params_in(DogScalars* s, float mn, float mx)
+{
+    s->mm_src[0] = mn; s->mm_src[1] = mx;
+    double smin = mn, smax = mx;
+    double scale = (1.0 - 0.0) * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
+    scale = (float)scale;
+    s->a = (float)scale;
+    s->b = (float)0.0 - (float)(smin * scale);
+    s->src_max_is_zero = smax == 0.0;
+}
+// normalize(diff, 0, 255, NORM_MINMAX, CV_8U): scale/shift in double, applied in float
+__device__ __forceinline__ void d_dog_params_out(DogScalars* s, float mn, float mx)
+{
+    s->mm_diff[0] = mn; s->mm_diff[1] = mx;
+    double dmin = mn, dmax = mx;
+    double scale = 255. * (dmax - dmin > DBL_EPSILON ? 1. / (dmax - dmin) : 0);
+    double shift = 0. - dmin * scale;
+    s->a8 = (float)scale;
+    s->b8 = (float)shift;
+}
+// the input's (min, max) came from the kernel that produced it
+__global__ void dog_params_in(DogScalars* s, const float* __restrict__ mm) { d_dog_params_in(s, mm[0], mm[1]); }
+
 // one block of 1024 threads folds all partial (min, max) pairs; 4 independent 8-byte loads per lane and step
 constexpr int MMF_T = 1024;
-__global__ __launch_bounds__(MMF_T) void minmax_final(const float* __restrict__ part, int nparts, float* __restrict__ out)
+// sc / what: the DOG scalars that follow from this (min, max) are computed by the same thread (what = 1: the input's
+// normalisation, 2: the difference image's) instead of by a kernel of their own
+__global__ __launch_bounds__(MMF_T) void minmax_final(const float* __restrict__ part, int nparts, float* __restrict__ out,
+                                                      DogScalars* __restrict__ sc, int what)
 {
     float lo = INFINITY, hi = -INFINITY;
     const float2* p2 = reinterpret_cast<const float2*>(part);
@@ -89,42 +125,16 @@ __global__ __launch_bounds__(MMF_T) void minmax_final(const float* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < MMF_T / 64; k++) { lo = fminf(lo, slo[k]); hi = fmaxf(hi, shi[k]); }
-        out[0] = lo; out[1] = hi;
+        if (out) { out[0] = lo; out[1] = hi; }
+        if (what == 1) d_dog_params_in(sc, lo, hi);
+        else if (what == 2) d_dog_params_out(sc, lo, hi);
     }
 }
 
 constexpr int MM_BLOCKS = 2048;
 
-// scalars of the DOG chain, produced and consumed on the device
-struct DogScalars {
-    float mm_src[2];   // min, max of the input
-    float mm_diff[2];  // min, max of hs - ls
-    float a, b;        // normalize(src, 0, 1, MINMAX, 32F):  v*a + b
-    float a8, b8;      // normalize(diff, 0, 255, MINMAX, 8U): v*a8 + b8
-    int src_max_is_zero;
-};
-
-// normalize(src, 0, 1, NORM_MINMAX, CV_32F): scale rounded to float, shift = (float)0 - (float)(smin*scale)
-__global__ void dog_params_in(DogScalars* s)
-{
-    double smin = s->mm_src[0], smax = s->mm_src[1];
-    double scale = (1.0 - 0.0) * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
-    scale = (float)scale;
-    s->a = (float)scale;
-    s->b = (float)0.0 - (float)(smin * scale);
-    s->src_max_is_zero = smax == 0.0;
-}
-// normalize(diff, 0, 255, NORM_MINMAX, CV_8U): scale/shift in double, applied in float
-__global__ void dog_params_out(DogScalars* s)
-{
-    double dmin = s->mm_diff[0], dmax = s->mm_diff[1];
-    double scale = 255. * (dmax - dmin > DBL_EPSILON ? 1. / (dmax - dmin) : 0);
-    double shift = 0. - dmin * scale;
-    s->a8 = (float)scale;
-    s->b8 = (float)shift;
-}
-
-int launch_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, float* part, float* out2)
+int launch_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, float* part, float* out2, DogScalars* sc = nullptr,
+                  int what = 0)
 {
     int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
     if (blocks > MM_BLOCKS) blocks = MM_BLOCKS;
@@ -132,7 +142,7 @@ int launch_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, float* part
     if (dtype == MA_U8) hipLaunchKernelGGL((minmax_partial<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)src, n, part);
     else if (dtype == MA_U16) hipLaunchKernelGGL((minmax_partial<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint16_t*)src, n, part);
     else hipLaunchKernelGGL((minmax_partial<float>), dim3(blocks), dim3(256), 0, ctx->stream, (const float*)src, n, part);
-    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, blocks, out2);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, blocks, out2, sc, what);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }
@@ -512,7 +522,7 @@ constexpr int DC_NW = 8;  // column pass: 64 columns x 8*R rows per block; R = 1
 
 int ma_launch_minmax_final(ma_ctx* ctx, const float* part, int nparts, float* out2)
 {
-    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, nparts, out2);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, nparts, out2, (DogScalars*)nullptr, 0);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }
@@ -589,12 +599,12 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
     MA_REQUIRE((h + DR - 1) / DR <= 65535, "image too tall");
 
     MaProfScope ps(ctx, MA_K_DOG, (double)n);
+    // the scalars of the two normalisations are computed by the last thread of the reduction they follow from
     if (src_minmax_dev) {  // the producer of `src` already reduced it
-        MA_HIP(hipMemcpyAsync(sc->mm_src, src_minmax_dev, 2 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc, src_minmax_dev);
     } else {
-        MA_TRY(launch_minmax(ctx, src, dtype, n, part, sc->mm_src));
+        MA_TRY(launch_minmax(ctx, src, dtype, n, part, nullptr, sc, 1));
     }
-    hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc);
     if (fused) {
         const dim3 grid(ma_xcd_grid((long long)nblk)), block(64 * DF_NW);
 #define MA_DOG_FUSED(T, SP)                                                                                                  \
@@ -629,8 +639,7 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
         else { if (fblur) MA_DOG_COLS(16, true); else MA_DOG_COLS(16, false); }
 #undef MA_DOG_COLS
     }
-    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, (int)nblk, sc->mm_diff);
-    hipLaunchKernelGGL(dog_params_out, dim3(1), dim3(1), 0, ctx->stream, sc);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, (int)nblk, (float*)nullptr, sc, 2);
     hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst, fscale);
     MA_HIP(hipGetLastError());
     if (src_max_is_zero_host) {

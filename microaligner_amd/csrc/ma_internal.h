@@ -74,6 +74,9 @@ void ma_pool_free(ma_ctx* ctx, void* p);
 // passed this point (nmi.hip)
 int ma_nmi_u8_enqueue(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk, double* scores_pinned_host,
                       int max_scores, int* n_scores);
+// the two halves of the gate in one pair of launches: NMI(a, b0) -> scores0, NMI(a, b1) -> scores1 (b1 may be NULL)
+int ma_nmi_u8_enqueue2(ma_ctx* ctx, const uint8_t* a, const uint8_t* b0, const uint8_t* b1, size_t n, size_t chunk,
+                       double* scores0_pinned_host, double* scores1_pinned_host, int max_scores, int* n_scores);
 
 int ma_ws_reserve(ma_ctx* ctx, size_t bytes);      // ensures ctx->ws has >= bytes
 int ma_pinned_reserve(ma_ctx* ctx, size_t bytes);

@@ -18,11 +18,15 @@ namespace {
 // on smooth DOG images.  Measured alternatives (profiles/r02_notes.md): two label bands of 32-bit counters 0.167 ms
 // per launch, this kernel 0.171, the four-band kernel 0.281.
 constexpr int HIST_SLICE16 = 65520;
+// blockIdx.z selects the second label image (b0 or b1: the "after" and the "before" half of the gate share `a` and one
+// launch); its histograms follow those of b0.
 template <int NT>
-__global__ __launch_bounds__(NT) void joint_hist16_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
-                                                          size_t n, size_t chunk, unsigned* __restrict__ hist)
+__global__ __launch_bounds__(NT) void joint_hist16_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b0,
+                                                          const uint8_t* __restrict__ b1, size_t n, size_t chunk,
+                                                          unsigned* __restrict__ hist)
 {
     extern __shared__ unsigned h[];              // [256 * 256 / 2]
+    const uint8_t* __restrict__ b = blockIdx.z ? b1 : b0;
     const size_t c0 = (size_t)blockIdx.y * chunk;
     const size_t c1 = c0 + chunk < n ? c0 + chunk : n;
     size_t s0 = c0 + (size_t)blockIdx.x * HIST_SLICE16;
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(NT) void joint_hist16_kernel(const uint8_t* __restr
     }
     for (size_t i = al + nvec * 16 + threadIdx.x; i < s1; i += NT) count(a[i], b[i]);
     __syncthreads();
-    unsigned* hh = hist + (size_t)blockIdx.y * 65536;
+    unsigned* hh = hist + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * 65536;
     for (int i = threadIdx.x; i < 32768; i += NT) {
         const unsigned c = h[i];
         if (c & 0xffffu) atomicAdd(&hh[2 * i], c & 0xffffu);
@@ -67,8 +71,9 @@ __device__ __forceinline__ double wave_sum(double v)
 // One block of 1024 threads per chunk: thread (q, j) owns column j of the rows [64q, 64q+64) of the chunk's
 // histogram, so the 2 x 65536 double-precision logarithms of a chunk are spread over 16 waves.
 constexpr int NR_T = 1024;
+// block b: histogram b, chunk b % nchunks (the histograms of a second label image follow those of the first)
 __global__ __launch_bounds__(NR_T) void nmi_reduce_kernel(const unsigned* __restrict__ hist, size_t n, size_t chunk,
-                                                          double* __restrict__ scores)
+                                                          unsigned nchunks, double* __restrict__ scores)
 {
     __shared__ unsigned paq[4][256], pbq[4][256];
     __shared__ unsigned pa[256], pb[256];
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(NR_T) void nmi_reduce_kernel(const unsigned* __rest
     __shared__ int cnt[2];
     const unsigned* hh = hist + (size_t)blockIdx.x * 65536;
     const int t = threadIdx.x, j = t & 255, q = t >> 8, lane = t & 63, w = t >> 6;
-    const size_t c0 = (size_t)blockIdx.x * chunk;
+    const size_t c0 = (size_t)(blockIdx.x % nchunks) * chunk;
     const double N = (double)((c0 + chunk < n ? c0 + chunk : n) - c0);
 
     if (t < 2) cnt[t] = 0;
@@ -158,34 +163,45 @@ __global__ __launch_bounds__(NR_T) void nmi_reduce_kernel(const unsigned* __rest
 
 } // namespace
 
-int ma_nmi_u8_enqueue(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk, double* scores_pinned_host,
-                      int max_scores, int* n_scores)
+// NMI(a, b0) and, when b1 is given, NMI(a, b1), chunk by chunk, in one pair of launches
+int ma_nmi_u8_enqueue2(ma_ctx* ctx, const uint8_t* a, const uint8_t* b0, const uint8_t* b1, size_t n, size_t chunk,
+                       double* scores0_pinned_host, double* scores1_pinned_host, int max_scores, int* n_scores)
 {
-    MA_REQUIRE(ctx && a && b && scores_pinned_host && n_scores, "NULL argument");
+    MA_REQUIRE(ctx && a && b0 && scores0_pinned_host && n_scores && (!b1 || scores1_pinned_host), "NULL argument");
     MA_REQUIRE(n > 0, "empty arrays");
     if (chunk == 0 || chunk > n) chunk = n;
     const size_t nchunks = (n + chunk - 1) / chunk;
+    const unsigned nimg = b1 ? 2 : 1;
     MA_REQUIRE(nchunks <= 65535 && (size_t)max_scores >= nchunks, "scores buffer too small");
     MA_REQUIRE(chunk < ((size_t)1 << 32), "chunk must be < 2^32 elements");
     MA_HIP(hipSetDevice(ctx->device));
-    const size_t hist_bytes = nchunks * 65536 * sizeof(unsigned);
-    const size_t total = hist_bytes + nchunks * sizeof(double);
+    const size_t hist_bytes = nimg * nchunks * 65536 * sizeof(unsigned);
+    const size_t total = hist_bytes + nimg * nchunks * sizeof(double);
     MA_TRY(ma_ws_reserve(ctx, total));
     unsigned* hist = (unsigned*)ctx->ws;
     double* scores = (double*)((char*)ctx->ws + hist_bytes);
     {
-        MaProfScope ps(ctx, MA_K_NMI, (double)n);
+        MaProfScope ps(ctx, MA_K_NMI, (double)n * nimg);
         MA_HIP(hipMemsetAsync(hist, 0, hist_bytes, ctx->stream));
         const size_t slices = (chunk + HIST_SLICE16 - 1) / HIST_SLICE16;
         MA_REQUIRE(slices <= 0x7fffffff, "chunk too large");
-        hipLaunchKernelGGL((joint_hist16_kernel<1024>), dim3((unsigned)slices, (unsigned)nchunks), dim3(1024),
-                           32768 * sizeof(unsigned), ctx->stream, a, b, n, chunk, hist);
-        hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)nchunks), dim3(NR_T), 0, ctx->stream, hist, n, chunk, scores);
+        hipLaunchKernelGGL((joint_hist16_kernel<1024>), dim3((unsigned)slices, (unsigned)nchunks, nimg), dim3(1024),
+                           32768 * sizeof(unsigned), ctx->stream, a, b0, b1, n, chunk, hist);
+        hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)(nimg * nchunks)), dim3(NR_T), 0, ctx->stream, hist, n, chunk,
+                           (unsigned)nchunks, scores);
         MA_HIP(hipGetLastError());
     }
-    MA_HIP(hipMemcpyAsync(scores_pinned_host, scores, nchunks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(hipMemcpyAsync(scores0_pinned_host, scores, nchunks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (b1)
+        MA_HIP(hipMemcpyAsync(scores1_pinned_host, scores + nchunks, nchunks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     *n_scores = (int)nchunks;
     return MA_OK;
+}
+
+int ma_nmi_u8_enqueue(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk, double* scores_pinned_host,
+                      int max_scores, int* n_scores)
+{
+    return ma_nmi_u8_enqueue2(ctx, a, b, nullptr, n, chunk, scores_pinned_host, nullptr, max_scores, n_scores);
 }
 
 extern "C" {

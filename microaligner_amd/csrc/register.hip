@@ -277,11 +277,11 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
             MA_TRY(warp_level(ctx, mov_lvl, dtype, h, w, this_flow, tile, ov, warped));
             MA_TRY(dog_level(ctx, warped.data.p, dtype, h, w, (const float*)warped.minmax.p, p.dog_flags, warped_dog));
             const size_t chunk = is_tiled(h, w, tile) ? (size_t)tile * tile : 0;   // similarity_scoring.py:27-50
-            MA_TRY(ma_nmi_u8_enqueue(ctx, (const uint8_t*)ref_dog.p, (const uint8_t*)warped_dog.p, npx, chunk, sc_after,
-                                     (int)max_chunks, &n_after));
             MA_TRY(dog_level(ctx, M.ptr, dtype, h, w, nullptr, p.dog_flags, raw_dog));
-            MA_TRY(ma_nmi_u8_enqueue(ctx, (const uint8_t*)ref_dog.p, (const uint8_t*)raw_dog.p, npx, chunk, sc_before,
-                                     (int)max_chunks, &n_before));
+            // both halves of the gate share the reference labels and one pair of launches
+            MA_TRY(ma_nmi_u8_enqueue2(ctx, (const uint8_t*)ref_dog.p, (const uint8_t*)warped_dog.p, (const uint8_t*)raw_dog.p,
+                                      npx, chunk, sc_after, sc_before, (int)max_chunks, &n_after));
+            n_before = n_after;
         }
         MA_HIP(hipStreamSynchronize(ctx->stream));   // the one host round trip of the level
         // the stream is idle: settle the per-kernel accounting now, so that its events are reused level after level
