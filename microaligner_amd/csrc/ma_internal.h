@@ -65,7 +65,15 @@ struct ma_ctx {
     std::unordered_map<void*, size_t> pool_live;
     // bytes moved by the explicit host <-> device copies of this ctx (ma_memcpy_*, ma_warp_pages_host)
     unsigned long long h2d_bytes = 0, d2h_bytes = 0;
+    // companion ctx (own stream and workspace, same device) for the work of ma_optflow_register that does not depend on
+    // the flow -- dog(ref) and dog(mov) of every level -- and the events that order the two streams; created on first use
+    ma_ctx* side = nullptr;
+    std::vector<hipEvent_t> sync_events;
 };
+// the companion ctx of `ctx` (created on first use; nullptr + error set on failure)
+ma_ctx* ma_ctx_side(ma_ctx* ctx);
+// event i of the ctx's pool of timing-free events for ordering its two streams (created on demand; nullptr on failure)
+hipEvent_t ma_ctx_sync_event(ma_ctx* ctx, size_t i);
 
 // device buffer from the ctx cache (64 KiB buckets); nullptr + error set on failure
 void* ma_pool_alloc(ma_ctx* ctx, size_t bytes);

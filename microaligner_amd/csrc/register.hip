@@ -115,13 +115,22 @@ int warp_level(ma_ctx* ctx, const void* img, int dtype, int h, int w, Flow& flow
     return ma_warp_tiled_minmax(ctx, img, dtype, h, w, flow.p, tile, overlap, out.data.p, (float*)out.minmax.p);
 }
 
-int dog_level(ma_ctx* ctx, const void* img, int dtype, int h, int w, const float* minmax_dev, int flags, Buf& out)
+int dog_level(ma_ctx* ctx, const void* img, int dtype, int h, int w, const float* minmax_dev, int flags, Buf& out,
+              ma_ctx* run_on = nullptr)
 {
-    // dog(img, True) inside register() (optflow_registrator.py:118-119,128-130): default sigmas 5 / 9
+    // dog(img, True) inside register() (optflow_registrator.py:118-119,128-130): default sigmas 5 / 9.  The result always
+    // comes from ctx's buffer cache; run_on: the ctx whose stream and workspace do the work (the companion, for the
+    // images that do not depend on the flow)
     out = Buf(ctx, (size_t)h * w);
     if (!out) return MA_ENOMEM;
-    return ma_dog_u8_ex(ctx, img, dtype, h, w, 5, 9, flags, minmax_dev, (uint8_t*)out.p, nullptr);
+    return ma_dog_u8_ex(run_on ? run_on : ctx, img, dtype, h, w, 5, 9, flags, minmax_dev, (uint8_t*)out.p, nullptr);
 }
+
+// waits for the companion stream before the buffers it writes can go back to the cache (error paths; a no-op otherwise)
+struct SideDrain {
+    ma_ctx* side;
+    ~SideDrain() { if (side) (void)hipStreamSynchronize(side->stream); }
+};
 
 int merge_level(ma_ctx* ctx, Flow& f1, Flow& f2, int h, int w, int tile, int overlap, float* out)
 {
@@ -229,6 +238,31 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
     double* sc_after = (double*)ctx->pinned;
     double* sc_before = sc_after + max_chunks;
 
+    // dog(ref) and dog(mov) of every level depend on the pyramids only: the companion stream computes them, coarsest level
+    // first, while this stream walks the levels -- the two full-resolution images are filtered under the coarse levels'
+    // Farneback, whose few windows leave most of the chip idle.  Events order the streams: the companion starts when the
+    // pyramids exist, every level waits for its two images.  Same kernels, same inputs: the results do not change.
+    ma_ctx* side = ma_ctx_side(ctx);
+    if (!side) return MA_EHIP;
+    std::vector<Buf> ref_dogs(n_lvl), raw_dogs(n_lvl);
+    SideDrain drain{side};   // declared after the buffers: destroyed (drained) before they are released
+    {
+        hipEvent_t ready = ma_ctx_sync_event(ctx, 0);
+        if (!ready) return MA_EHIP;
+        MA_HIP(hipEventRecord(ready, ctx->stream));
+        MA_HIP(hipStreamWaitEvent(side->stream, ready, 0));
+        for (int lvl = 0; lvl < n_lvl; lvl++) {
+            const Level& R = ref_pyr[lvl];
+            const Level& M = mov_pyr[lvl];
+            hipEvent_t e_ref = ma_ctx_sync_event(ctx, 1 + 2 * (size_t)lvl), e_raw = ma_ctx_sync_event(ctx, 2 + 2 * (size_t)lvl);
+            if (!e_ref || !e_raw) return MA_EHIP;
+            MA_TRY(dog_level(ctx, R.ptr, dtype, R.h, R.w, nullptr, p.dog_flags, ref_dogs[lvl], side));
+            MA_HIP(hipEventRecord(e_ref, side->stream));
+            MA_TRY(dog_level(ctx, M.ptr, dtype, M.h, M.w, nullptr, p.dog_flags, raw_dogs[lvl], side));
+            MA_HIP(hipEventRecord(e_raw, side->stream));
+        }
+    }
+
     Flow m_flow;   // the merged flow carried from level to level
     for (int lvl = 0; lvl < n_lvl; lvl++) {
         const bool last = lvl == n_lvl - 1;
@@ -247,8 +281,8 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
             mov_lvl_mm = (const float*)pre.minmax.p;
         }
         // the gate always needs dog(ref); with use_dog it doubles as the Farneback input (:118-119,128)
-        Buf ref_dog;
-        MA_TRY(dog_level(ctx, R.ptr, dtype, h, w, nullptr, p.dog_flags, ref_dog));
+        Buf ref_dog = std::move(ref_dogs[lvl]);
+        MA_HIP(hipStreamWaitEvent(ctx->stream, ma_ctx_sync_event(ctx, 1 + 2 * (size_t)lvl), 0));
         // a single level at full resolution: its flow is the result if accepted, so it is computed in the caller's buffer
         Flow this_flow;
         if (last && lvl == 0 && h == H && w == W) {
@@ -273,11 +307,11 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
         int n_after = 0, n_before = 0;
         {
             Warped warped;
-            Buf warped_dog, raw_dog;
+            Buf warped_dog, raw_dog = std::move(raw_dogs[lvl]);
             MA_TRY(warp_level(ctx, mov_lvl, dtype, h, w, this_flow, tile, ov, warped));
             MA_TRY(dog_level(ctx, warped.data.p, dtype, h, w, (const float*)warped.minmax.p, p.dog_flags, warped_dog));
             const size_t chunk = is_tiled(h, w, tile) ? (size_t)tile * tile : 0;   // similarity_scoring.py:27-50
-            MA_TRY(dog_level(ctx, M.ptr, dtype, h, w, nullptr, p.dog_flags, raw_dog));
+            MA_HIP(hipStreamWaitEvent(ctx->stream, ma_ctx_sync_event(ctx, 2 + 2 * (size_t)lvl), 0));
             // both halves of the gate share the reference labels and one pair of launches
             MA_TRY(ma_nmi_u8_enqueue2(ctx, (const uint8_t*)ref_dog.p, (const uint8_t*)warped_dog.p, (const uint8_t*)raw_dog.p,
                                       npx, chunk, sc_after, sc_before, (int)max_chunks, &n_after));
