@@ -600,6 +600,10 @@ def main():
             "roofline_polyexp": kernels.get("polyexp_m0"),
             "kernels": kernels,
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 3),
+            "kernel_time_note": "sum of the launch durations on BOTH streams of the context: the dog() of the reference and "
+                                "the moving image of every level run on a low-priority companion stream under the level "
+                                "loop (register.hip), so the sum exceeds the step and launches that share the chip are "
+                                "longer than they would be alone",
             "step_ms_host": step_ms_host,
             "sustained_clock_ghz": round(clock_ghz, 3),
             "library": ctx.lib.ma_version().decode(),
