@@ -296,8 +296,15 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
             const void *fb_ref = R.ptr, *fb_mov = mov_lvl;
             int fb_dtype = dtype;
             if (p.use_dog) {
-                MA_TRY(dog_level(ctx, mov_lvl, dtype, h, w, mov_lvl_mm, p.dog_flags, mov_dog));
-                fb_ref = ref_dog.p; fb_mov = mov_dog.p; fb_dtype = MA_U8;
+                if (lvl == 0) {
+                    // the first level's moving image IS the raw one: its dog() is the companion stream's
+                    MA_HIP(hipStreamWaitEvent(ctx->stream, ma_ctx_sync_event(ctx, 2), 0));
+                    fb_mov = raw_dogs[0].p;
+                } else {
+                    MA_TRY(dog_level(ctx, mov_lvl, dtype, h, w, mov_lvl_mm, p.dog_flags, mov_dog));
+                    fb_mov = mov_dog.p;
+                }
+                fb_ref = ref_dog.p; fb_dtype = MA_U8;
             }
             // prev = moving image, next = reference image (flow_calc.py:34-35)
             MA_TRY(ma_farneback_tiled(ctx, fb_mov, fb_ref, fb_dtype, h, w, tiled ? tile : 0, tiled ? ov : 0, win,
