@@ -118,6 +118,34 @@ def test_c_level_loop_equals_the_python_level_loop(unrelated, dtype, params):
     assert np.array_equal(out["c"][0], exp) and [r[4] for r in out["c"][1]] == [r[3] for r in reports]
 
 
+def test_two_streams_reuse_cached_buffers_without_races(ctx):
+    """ma_optflow_register runs the flow-independent dog() calls on a companion stream into buffers of the context's
+    cache.  Pairs of different sizes and parameters registered back to back, device resident, never synchronised in
+    between (so the cache hands buffers of one call to the other stream of the next while kernels are still in flight):
+    every repetition must reproduce the first result of its pair bit for bit, and that result is the oracle's."""
+    cases = [((700, 900), np.float32, dict(num_pyr_lvl=3, use_full_res_img=True, use_dog=True, tile_size=200, overlap=40)),
+             ((1300, 1100), np.uint8, dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True, tile_size=400, overlap=60)),
+             ((512, 512), np.uint16, dict(num_pyr_lvl=2, use_full_res_img=False, use_dog=False, tile_size=1000, overlap=100)),
+             ((900, 700), np.float32, dict(num_pyr_lvl=1, use_full_res_img=True, use_dog=True, tile_size=300, overlap=50))]
+    pairs = [synthetic.make_pair(h, w, 3 + k, dt) for k, ((h, w), dt, _) in enumerate(cases)]
+    dev = [(ctx.asdevice(r), ctx.asdevice(m)) for r, m in pairs]
+    first = [None] * len(cases)
+    pending = []
+    for rep in range(6):
+        for k in (0, 1, 2, 3, 1, 0, 3, 2)[rep % 2:]:
+            reg = make_reg(cases[k][2])
+            reg.ref_img, reg.mov_img = dev[k]
+            pending.append((k, reg.register()))          # a DeviceArray: nothing waits for the kernels here
+    for k, flow in pending:
+        got = flow.numpy()
+        if first[k] is None:
+            first[k] = got
+        assert np.array_equal(got, first[k]), k
+    for k in (0, 2):
+        exp, _ = RO.register(pairs[k][0], pairs[k][1], **cases[k][2])
+        assert np.array_equal(first[k], exp)
+
+
 def test_a_plain_c_host_drives_the_whole_path(tmp_path):
     """tests/c_host/register_host.c: a C program that knows only include/microaligner_hip.h (compiled here with gcc, linked
     against libmicroaligner_hip.so) registers and warps a pair through ma_optflow_register + ma_warp_tiled; its flow,
