@@ -299,6 +299,46 @@ def host_inclusive_leg(steps, ref, mov, params):
     return dt
 
 
+def host_stream_leg(n_pairs, ref, mov, params, dtype):
+    """A STREAM of distinct numpy pairs through parallel.stream_pairs (numpy in -> numpy out, the way real inputs arrive:
+    __main__.py:398-433 reads pages from TIFF): one context, H2D of pair k+1 and D2H of pair k-1 under the kernels of pair
+    k.  Returns ms per pair sustained and the per-engine busy times per pair.  The pairs are made distinct by rolling the
+    synthetic pair along y (same statistics, different bytes: nothing can be recognised as already uploaded)."""
+    import numpy as np
+    from microaligner_amd import parallel
+    from microaligner_amd.device import get_context
+    ctx = get_context()
+    ctx.forget_host_arrays()
+
+    def cast(a):
+        return a if a.dtype == dtype else np.clip(np.rint(a), 0, 255).astype(dtype)
+
+    pairs = [(cast(np.roll(ref, 53 * k, axis=0)), cast(np.roll(mov, 53 * k, axis=0))) for k in range(n_pairs)]
+    for _ in parallel.stream_pairs(pairs[:3], params, warp=True):      # warm-up: slots, page-locked result buffers
+        pass
+    stats = {}
+    t0 = time.perf_counter()
+    checks, marks = [], []
+    for res in parallel.stream_pairs(pairs, params, warp=True, stats=stats):
+        marks.append(time.perf_counter())
+        checks.append((float(res.flow[::997, ::991].sum()), int(res.warped[::997, ::991].astype(np.int64).sum())))
+    wall = (marks[-1] - t0) / n_pairs               # includes filling and draining the pipeline once
+    half = n_pairs // 2                             # sustained: arrival interval over the later half of the stream
+    dt = (marks[-1] - marks[half - 1]) / (n_pairs - half)
+    in_bytes = sum(a.nbytes + b.nbytes for a, b in pairs)
+    H, W = ref.shape
+    out_bytes = n_pairs * (H * W * 8 + H * W * np.dtype(dtype).itemsize)
+    return {"value": round(H * W / dt / 1e6, 2), "unit": "Mpix/s", "ms_per_pair": round(dt * 1e3, 3),
+            "ms_per_pair_incl_fill_and_drain": round(wall * 1e3, 3), "pairs": n_pairs,
+            "dtype": np.dtype(dtype).name,
+            "engine_busy_ms_per_pair": {k: round(stats[k] / n_pairs, 3) for k in ("h2d_busy_ms", "compute_busy_ms", "d2h_busy_ms")},
+            "every_byte_moved_once": stats["h2d_bytes"] == in_bytes and stats["d2h_bytes"] == out_bytes,
+            "h2d_gb_per_pair": round(stats["h2d_bytes"] / n_pairs / 1e9, 3), "d2h_gb_per_pair": round(stats["d2h_bytes"] / n_pairs / 1e9, 3),
+            "distinct_results": len(set(checks)),
+            "what": "parallel.stream_pairs over distinct numpy pairs: upload / kernels / download of consecutive pairs "
+                    "overlapped on three engines of one context, results delivered as numpy arrays in input order"}
+
+
 # ---- launcher ----------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -380,6 +420,11 @@ def main():
                     help="edge of the CPU-baseline sample; 0: the full workload on hosts with >= 128 hardware threads "
                          "(the 16384^2 oracle run takes ~45 s there), else 4096")
     ap.add_argument("--lanes", type=int, default=3, help="pairs in flight for the informational multi-lane leg (0: skip)")
+    ap.add_argument("--stream-pairs", type=int, default=12,
+                    help="distinct pairs of the informational numpy -> numpy stream leg (parallel.stream_pairs; 0: skip)")
+    ap.add_argument("--no-companion", action="store_true",
+                    help="MA_OPT_COMPANION_STREAM = 0: every kernel alone on the chip (per-kernel timings comparable from "
+                         "run to run; the step is ~3 ms longer)")
     ap.add_argument("--feature-init", action="store_true",
                     help="cfg5: FeatureRegistrator.register() supplies the affine initialisation inside the timed step")
     ap.add_argument("--pairs-total", type=int, default=0,
@@ -459,7 +504,14 @@ def main():
     # JSON line states (`devices`)
     dev_index = local_rank % ndev
     os.environ["MICROALIGNER_DEVICE"] = str(dev_index)   # what get_context() inside register()/warp() picks up
+    # one process per GPU, next to its GPU: the CPUs of the device's NUMA node (page-locked buffers and the pages the input
+    # synthesis first touches are then local to the GPU's PCIe root: SURVEY 8e, "per-rank affinity")
+    from microaligner_amd.device import bind_to_device_numa, set_affinity
+    all_cpus = sorted(os.sched_getaffinity(0))
+    bound_cpus = bind_to_device_numa(dev_index)
     ctx = get_context()
+    if args.no_companion:
+        ctx.companion_stream = False
 
     np_dtype = np.uint8 if args.dtype == "u8" else np.float32
     freg = None
@@ -556,6 +608,8 @@ def main():
     rows = rank_table(dist, world, rank, {
         "rank": rank, "device": dev_index, "pci_bus_id": info["pci_bus_id"], "name": info["name"],
         "hbm_free_gb": round(info["mem_free"] / 2 ** 30, 1), "hbm_total_gb": round(info["mem_total"] / 2 ** 30, 1),
+        "cpus": (f"{bound_cpus[0]}-{bound_cpus[-1]} ({len(bound_cpus)} of {len(all_cpus)}, local to the device)"
+                 if bound_cpus else f"all {len(all_cpus)} (no NUMA binding: topology unknown or single node)"),
         "pairs": my_pairs, "ms_per_step": round((t1 - t0) / args.steps * 1e3, 3), "clock_ghz": round(clock_ghz, 3),
         "result": summary})
     gather_ms = (time.perf_counter() - tg0) * 1e3
@@ -618,13 +672,21 @@ def main():
             # never the headline value)
             th = host_inclusive_leg(max(1, min(args.steps, 3)), ref, mov if inv_affine is None else
                                     ctx.warp_affine(dmov, inv_affine).numpy(), params)
-            if freg is None:
-                del ref, mov
             res["variants"]["host_inclusive"] = {"value": round(H * W / th / 1e6, 2), "unit": "Mpix/s",
                                                  "ms_per_step": round(th * 1e3, 3),
-                                                 "what": "numpy in -> numpy out, the reference's statements: H2D of ref and mov, register(), D2H of the "
-                                                         "flow, Warper.warp(mov, flow) (both recognised as resident: no second upload), D2H of "
-                                                         "the warped image"}
+                                                 "what": "numpy in -> numpy out, ONE pair, the reference's statements: H2D of ref and mov, register(), "
+                                                         "D2H of the flow, Warper.warp(mov, flow) (the flow register() returned is recognised as "
+                                                         "resident; the caller's writable mov array is uploaded again), D2H of the warped image; "
+                                                         "nothing overlaps: see host_stream for the sustained rate"}
+
+            if args.stream_pairs > 0 and inv_affine is None:
+                # informational: the sustained numpy -> numpy rate over a stream of distinct pairs (PCIe inclusive; never
+                # the headline value), in the workload's dtype and in the pipeline-faithful uint8
+                res["variants"]["host_stream"] = host_stream_leg(args.stream_pairs, ref, mov, params, np_dtype)
+                if np_dtype != np.uint8:
+                    res["variants"]["host_stream_u8"] = host_stream_leg(args.stream_pairs, ref, mov, params, np.uint8)
+            if freg is None:
+                del ref, mov
 
             def timed_steps():
                 step()
@@ -658,6 +720,7 @@ def main():
                     "value": round(H * W / tl / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(tl * 1e3, 3),
                     "pairs_in_flight": args.lanes}
         if world == 1 and not args.no_cpu_baseline and not args.pairs_total:
+            set_affinity(all_cpus)      # the CPU baseline uses every core of the host, not just the GPU's node
             sample = args.cpu_sample or (H if (os.cpu_count() or 1) >= 128 else 4096)
             res["cpu_baseline"] = cpu_baseline(min(sample, H), params)
         print(json.dumps(res))

@@ -79,6 +79,41 @@ int ma_ctx_trim(ma_ctx* ctx);
  * check that a loop such as warp_and_save_pages (__main__.py:288-302) uploads its flow once, not once per page. */
 int ma_ctx_transfer_stats(ma_ctx* ctx, unsigned long long* h2d_bytes, unsigned long long* d2h_bytes, int reset);
 
+/* Run-time switches of a ctx.  MA_OPT_COMPANION_STREAM (default 1): ma_optflow_register computes the dog() of the
+ * reference and of the moving image of every level on a second, low-priority HIP stream under the level loop; 0 keeps
+ * everything on the ctx stream (same kernels, same inputs, same results -- for alone-on-the-chip kernel timings that are
+ * comparable from run to run).  MA_OPT_WORKSPACE_LIMIT: same as ma_ctx_set_workspace_limit. */
+enum ma_option { MA_OPT_COMPANION_STREAM = 1, MA_OPT_WORKSPACE_LIMIT = 2 };
+int ma_ctx_set_option(ma_ctx* ctx, int option, long long value);
+int ma_ctx_get_option(ma_ctx* ctx, int option, long long* value);
+
+/* ---- transfer engines -------------------------------------------------------
+ * A stream of pairs arrives from the host and leaves to the host (the reference reads every page from TIFF and writes
+ * every result back, __main__.py:398-433; one page in memory at a time, README.md:5).  To keep the kernels of pair k,
+ * the upload of pair k+1 and the download of pair k-1 in flight together a ctx owns two more HIP streams besides its
+ * compute stream: MA_ENGINE_H2D and MA_ENGINE_D2H.  Copies issued through ma_engine_memcpy_* run on the named engine's
+ * stream and return when THAT copy is complete (the calling host thread waits for its own copy only: pageable host
+ * memory is staged by the runtime, page-locked memory from ma_host_alloc goes by DMA); events order the engines:
+ * ma_engine_record(ctx, e, ev) marks the work enqueued on engine e so far, ma_engine_wait(ctx, e, ev) makes everything
+ * enqueued on engine e afterwards wait for it (no host wait).  ev: from ma_event_create.  The three engines of one ctx
+ * may be driven from three host threads (one per engine); the counters behind ma_ctx_transfer_stats are atomic.
+ * microaligner_amd.parallel.stream_pairs is the pipeline built on this. */
+enum ma_engine { MA_ENGINE_COMPUTE = 0, MA_ENGINE_H2D = 1, MA_ENGINE_D2H = 2 };
+int ma_engine_memcpy_h2d(ma_ctx* ctx, int engine, void* dst, const void* src_host, size_t bytes);
+int ma_engine_memcpy_d2h(ma_ctx* ctx, int engine, void* dst_host, const void* src, size_t bytes);
+int ma_engine_record(ma_ctx* ctx, int engine, void* ev);
+int ma_engine_wait(ma_ctx* ctx, int engine, void* ev);
+int ma_engine_sync(ma_ctx* ctx, int engine);
+/* Pageable host memory handed to ma_engine_memcpy_* on a transfer engine is staged by the library itself: a ring of
+ * page-locked 32 MiB chunks per direction, filled / drained by a small pool of host threads
+ * (MICROALIGNER_COPY_THREADS, default 8 on hosts with >= 32 hardware threads) while the DMA engine moves the previous
+ * chunk, so that the device only ever sees page-locked copies (the runtime's own staging of pageable memory shares
+ * the shader engines with running kernels).  ma_host_parallel_copy is that pool's memcpy, exported so that it can be
+ * checked without a GPU.  Host-only. */
+int ma_host_parallel_copy(void* dst, const void* src, size_t bytes);
+/* Host wait for an event (any engine). */
+int ma_event_sync(ma_ctx* ctx, void* ev);
+
 /* Identity of a device, for the per-rank lines of a multi-GPU run: marketing name, PCI bus id ("0000:c1:00.0"), free
  * and total HBM in bytes, compute units.  Any output pointer may be NULL.  Needs no ctx. */
 int ma_device_info(int device, char* name, size_t name_len, char* pci_bus_id, size_t pci_len, size_t* mem_free,

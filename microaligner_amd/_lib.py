@@ -15,6 +15,8 @@ MA_FB_MULADD_FUSED = 1
 MA_KNN_AUTO, MA_KNN_EXACT, MA_KNN_FILTERED = 0, 1, 2   # enum ma_knn_mode
 MA_DOG_FUSED_BLUR, MA_DOG_FUSED_SCALE = 1, 2
 MA_FLOW_CELL_REPLICAS = 8
+MA_OPT_COMPANION_STREAM, MA_OPT_WORKSPACE_LIMIT = 1, 2      # enum ma_option
+MA_ENGINE_COMPUTE, MA_ENGINE_H2D, MA_ENGINE_D2H = 0, 1, 2   # enum ma_engine
 
 KERNEL_IDS = {"polyexp_m0": 0, "blur_v": 1, "blur_h_solve": 2, "warp": 3, "merge": 4, "pyr_down": 5,
               "pyr_up": 6, "dog": 7, "nmi": 8, "other": 9}
@@ -99,6 +101,15 @@ SIGNATURES.update({
     "ma_cut_tiles_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ma_device_info": (_i, [_i, C.c_char_p, _sz, C.c_char_p, _sz, C.POINTER(_sz), C.POINTER(_sz), C.POINTER(_i)]),
     "ma_clock_probe": (_i, [_vp, _d, C.POINTER(_d)]),
+    "ma_ctx_set_option": (_i, [_vp, _i, C.c_longlong]),
+    "ma_ctx_get_option": (_i, [_vp, _i, C.POINTER(C.c_longlong)]),
+    "ma_engine_memcpy_h2d": (_i, [_vp, _i, _vp, _vp, _sz]),
+    "ma_engine_memcpy_d2h": (_i, [_vp, _i, _vp, _vp, _sz]),
+    "ma_engine_record": (_i, [_vp, _i, _vp]),
+    "ma_engine_wait": (_i, [_vp, _i, _vp]),
+    "ma_engine_sync": (_i, [_vp, _i]),
+    "ma_event_sync": (_i, [_vp, _vp]),
+    "ma_host_parallel_copy": (_i, [_vp, _vp, _sz]),
 })
 
 _lib = None

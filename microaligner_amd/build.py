@@ -48,9 +48,11 @@ def source_hash():
     traffic from a summary whose hash is the loaded library's."""
     import hashlib
     h = hashlib.sha256()
-    # no kernel of the measured path (cfg3: pyramid, DOG, Farneback, warp, merge, NMI) lives in these: host code, the
-    # clock probe, and the feature stage (FAST / DAISY / 2-NN / affine warp), which has its own tests and timings
-    off_path = {"ma_api.hip", "register.hip", "probe.hip", "knn.hip", "daisy.hip", "affine.hip"}
+    # register.hip decides which launches the measured path makes and on which stream, ma_api.hip how the buffer cache and
+    # the streams behave: both are part of what a profile measures.  Left out: the clock probe and the feature stage
+    # (FAST / DAISY / 2-NN / affine warp), which has its own tests and timings and no kernel on the measured path (cfg3:
+    # pyramid, DOG, Farneback, warp, merge, NMI)
+    off_path = {"probe.hip", "knn.hip", "daisy.hip", "affine.hip"}
     for path in [os.path.join(CSRC, s) for s in SOURCES if s not in off_path] + HEADERS:
         h.update(open(path, "rb").read())
     h.update(" ".join(_flags()).encode())

@@ -518,7 +518,42 @@ int grid_for(size_t n) { size_t b = (n + 256 * 4 - 1) / (256 * 4); return (int)(
 constexpr int DC_NW = 8;  // column pass: 64 columns x 8*R rows per block; R = 10 when r % 10 == 0 (no tail taps) else 16
                           // (8 waves x 10 rows measured 2 % faster than 4 x 20, profiles/r01_notes.md)
 
+// launch geometry and workspace of one dog() call
+struct DogPlan {
+    bool fused;
+    int nstrips, LY, nseg;
+    dim3 cgrid;
+    size_t nblk, npart, bytes;
+};
+DogPlan dog_plan(int h, int w, int low_sigma)
+{
+    DogPlan p;
+    const size_t n = (size_t)h * w;
+    const int ksize = low_sigma * 4 * 2 + 1;
+    const int r = ksize / 2;
+    const int DC_R = (r % 10 == 0) ? 10 : 16;
+    p.fused = ksize == DF_KS;
+    p.nstrips = (w + 63) / 64;
+    // rows per block: enough blocks to fill 256 CUs x 2 a few times over, few enough that the 42 halo rows a block
+    // filters before its first output row stay a small fraction
+    {
+        const int want_seg = std::max(1, 1536 / p.nstrips);
+        p.LY = (int)ma_align_up((size_t)std::max(1, (h + want_seg - 1) / want_seg), DF_S);
+        if (p.LY < 4 * DF_S) p.LY = std::min(4 * DF_S, (int)ma_align_up((size_t)h, DF_S));
+    }
+    p.nseg = (h + p.LY - 1) / p.LY;
+    // workspace: [tlo, thi,] diff (f32 each), block partials, scalars
+    p.cgrid = dim3((w + 63) / 64, (h + DC_NW * DC_R - 1) / (DC_NW * DC_R));
+    p.nblk = p.fused ? (size_t)p.nstrips * p.nseg : (size_t)p.cgrid.x * p.cgrid.y;
+    p.npart = p.nblk > MM_BLOCKS ? p.nblk : MM_BLOCKS;
+    const size_t nimg = p.fused ? 1 : 3;
+    p.bytes = n * nimg * sizeof(float) + p.npart * 2 * sizeof(float) + 256 + 16;
+    return p;
+}
+
 } // namespace
+
+size_t ma_dog_workspace_bytes(int h, int w, int low_sigma) { return dog_plan(h, w, low_sigma).bytes; }
 
 int ma_launch_minmax_final(ma_ctx* ctx, const float* part, int nparts, float* out2)
 {
@@ -573,23 +608,10 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
     MA_TRY(ma_const_table(ctx, ((uint64_t)3 << 56) | key | (uint64_t)high_sigma, chi.data(), chi.size(), &dhic));
 
     // The reference's kernel size (41: sigmas 5 / 9) takes the fused kernel; other sizes the two-kernel chain.
-    const bool fused = ksize == DF_KS;
-    const int nstrips = (w + 63) / 64;
-    // rows per block: enough blocks to fill 256 CUs x 2 a few times over, few enough that the 42 halo rows a block
-    // filters before its first output row stay a small fraction
-    int LY = h;
-    {
-        const int want_seg = std::max(1, 1536 / nstrips);
-        LY = (int)ma_align_up((size_t)std::max(1, (h + want_seg - 1) / want_seg), DF_S);
-        if (LY < 4 * DF_S) LY = std::min(4 * DF_S, (int)ma_align_up((size_t)h, DF_S));
-    }
-    const int nseg = (h + LY - 1) / LY;
-    // workspace: [tlo, thi,] diff (f32 each), block partials, scalars
-    const dim3 cgrid((w + 63) / 64, (h + DC_NW * DC_R - 1) / (DC_NW * DC_R));
-    const size_t nblk = fused ? (size_t)nstrips * nseg : (size_t)cgrid.x * cgrid.y;
-    const size_t npart = nblk > MM_BLOCKS ? nblk : MM_BLOCKS;
-    const size_t nimg = fused ? 1 : 3;
-    const size_t bytes = n * nimg * sizeof(float) + npart * 2 * sizeof(float) + 256 + 16;
+    const DogPlan pl = dog_plan(h, w, low_sigma);
+    const bool fused = pl.fused;
+    const int nstrips = pl.nstrips, LY = pl.LY, nseg = pl.nseg;
+    const size_t nblk = pl.nblk, npart = pl.npart, bytes = pl.bytes;
     MA_TRY(ma_ws_reserve(ctx, bytes));
     float* tlo = (float*)ctx->ws;
     float* thi = tlo + n;

@@ -2,10 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -14,6 +16,7 @@
 #include "../../include/microaligner_hip.h"
 
 void ma_set_error(const char* fmt, ...);
+struct MaStageRing;   // ring of page-locked chunks for staged transfers of pageable memory (ma_api.hip)
 
 #define MA_HIP(expr)                                                                          \
     do {                                                                                      \
@@ -63,8 +66,15 @@ struct ma_ctx {
     // stream-ordered reuse on the ctx stream, returned to the driver by ma_ctx_trim / ma_ctx_destroy
     std::multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_live;
-    // bytes moved by the explicit host <-> device copies of this ctx (ma_memcpy_*, ma_warp_pages_host)
-    unsigned long long h2d_bytes = 0, d2h_bytes = 0;
+    // bytes moved by the explicit host <-> device copies of this ctx (ma_memcpy_*, ma_engine_memcpy_*,
+    // ma_warp_pages_host); atomic: the transfer engines are driven from their own host threads
+    std::atomic<unsigned long long> h2d_bytes{0}, d2h_bytes{0};
+    // transfer engines (MA_ENGINE_H2D / MA_ENGINE_D2H): streams created on first use under `mu`
+    hipStream_t engine[3] = {nullptr, nullptr, nullptr};
+    std::mutex mu;
+    MaStageRing* stage[2] = {nullptr, nullptr};   // [0] host -> device, [1] device -> host; each used by one thread at a time
+    // MA_OPT_COMPANION_STREAM
+    bool companion = true;
     // companion ctx (own stream and workspace, same device) for the work of ma_optflow_register that does not depend on
     // the flow -- dog(ref) and dog(mov) of every level -- and the events that order the two streams; created on first use
     ma_ctx* side = nullptr;
@@ -72,6 +82,9 @@ struct ma_ctx {
 };
 // the companion ctx of `ctx` (created on first use; nullptr + error set on failure)
 ma_ctx* ma_ctx_side(ma_ctx* ctx);
+void ma_stage_rings_destroy(ma_ctx* ctx);
+// stream of an engine (MA_ENGINE_*); nullptr + error set on failure
+hipStream_t ma_engine_stream(ma_ctx* ctx, int engine);
 // event i of the ctx's pool of timing-free events for ordering its two streams (created on demand; nullptr on failure)
 hipEvent_t ma_ctx_sync_event(ma_ctx* ctx, size_t i);
 
@@ -87,6 +100,8 @@ int ma_nmi_u8_enqueue2(ma_ctx* ctx, const uint8_t* a, const uint8_t* b0, const u
                        double* scores0_pinned_host, double* scores1_pinned_host, int max_scores, int* n_scores);
 
 int ma_ws_reserve(ma_ctx* ctx, size_t bytes);      // ensures ctx->ws has >= bytes
+// workspace one dog() call of an (h, w) image takes from ctx->ws (dog.hip)
+size_t ma_dog_workspace_bytes(int h, int w, int low_sigma);
 int ma_pinned_reserve(ma_ctx* ctx, size_t bytes);
 int ma_dconst_reserve(ma_ctx* ctx, size_t bytes);
 // immutable device copies of small float tables (filter taps), cached per (device, key) for the process lifetime

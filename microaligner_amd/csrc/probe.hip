@@ -59,7 +59,11 @@ int ma_device_info(int device, char* name, size_t name_len, char* pci_bus_id, si
     MA_REQUIRE(device >= 0 && device < n, "device index out of range");
     hipDeviceProp_t prop;
     MA_HIP(hipGetDeviceProperties(&prop, device));
-    if (name && name_len) { std::strncpy(name, prop.name, name_len - 1); name[name_len - 1] = 0; }
+    if (name && name_len) {
+        // some driver stacks leave the marketing name empty: fall back to the ISA name so that a rank row is never anonymous
+        if (prop.name[0]) std::snprintf(name, name_len, "%s", prop.name);
+        else std::snprintf(name, name_len, "AMD GPU (%s, %d CUs)", prop.gcnArchName, prop.multiProcessorCount);
+    }
     if (pci_bus_id && pci_len) MA_HIP(hipDeviceGetPCIBusId(pci_bus_id, (int)pci_len, device));
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (mem_free || mem_total) {

@@ -242,10 +242,22 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
     // first, while this stream walks the levels -- the two full-resolution images are filtered under the coarse levels'
     // Farneback, whose few windows leave most of the chip idle.  Events order the streams: the companion starts when the
     // pyramids exist, every level waits for its two images.  Same kernels, same inputs: the results do not change.
-    ma_ctx* side = ma_ctx_side(ctx);
+    // MA_OPT_COMPANION_STREAM = 0: the same launches in the same order on the ctx stream itself (every kernel alone on the
+    // chip: the per-kernel timings of a profile are then comparable from run to run)
+    ma_ctx* side = ctx->companion ? ma_ctx_side(ctx) : ctx;
     if (!side) return MA_EHIP;
+    {
+        // the companion's workspace is sized ONCE, for its largest image, before anything is enqueued on it: growing it
+        // level by level would wait for the stream (and reallocate) n_lvl times inside this prologue
+        size_t need = 0;
+        for (const Level& L : ref_pyr) {
+            const size_t b = ma_dog_workspace_bytes(L.h, L.w, 5);
+            if (b > need) need = b;
+        }
+        MA_TRY(ma_ws_reserve(side, need));
+    }
     std::vector<Buf> ref_dogs(n_lvl), raw_dogs(n_lvl);
-    SideDrain drain{side};   // declared after the buffers: destroyed (drained) before they are released
+    SideDrain drain{side != ctx ? side : nullptr};   // declared after the buffers: destroyed (drained) before they are released
     {
         hipEvent_t ready = ma_ctx_sync_event(ctx, 0);
         if (!ready) return MA_EHIP;

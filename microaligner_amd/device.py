@@ -61,16 +61,19 @@ class DeviceArray:
         when the last reference to it (or to a view of it) is dropped.  `out`: a C-contiguous array of the same
         shape and dtype to fill instead (e.g. a row of the caller's memmap)."""
         self._check_alive()
-        if out is None:
+        own = out is None
+        if own:
             out = self.ctx.host_empty(self.shape, self.dtype)
         elif (tuple(out.shape) != self.shape or out.dtype != self.dtype or not out.flags.c_contiguous
               or not out.flags.writeable):
             raise ValueError(f"out must be a writable C-contiguous {self.dtype} array of shape {self.shape}")
         if out.nbytes:
             L.check(self.ctx.lib.ma_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes))
-        self.ctx._resident.remember(out, self)   # asdevice(out) will find this array instead of uploading it again
-        if self.ctx._resident.mode == "readonly" and self.ctx._resident._eligible(out):
-            out.flags.writeable = False          # the hard form of the write guard: results cannot be edited in place
+        if own and self.ctx._resident.mode == "results":
+            # results are handed out read-only (the flags of a caller's `out` array are never touched): that is what
+            # lets asdevice(out) find this device array again instead of uploading the bytes it has just downloaded
+            self.ctx._resident.freeze(out)
+        self.ctx._resident.remember(out, self)
         return out
 
     def _check_alive(self):
@@ -120,17 +123,24 @@ class _ResidentCache:
     The reference's callers move every array through numpy: register() returns the flow, the very next statement
     hands it to Warper (microaligner/__main__.py:418-433), and warp_and_save_pages sets the same flow on the warper
     for every page of a cycle (:296-301).  Through a drop-in API that is one 2.1 GB upload per call at 16384^2.  This
-    cache lets Context.asdevice() recognise a host array it has uploaded or downloaded before and return the device
-    array that is still alive instead:
+    cache lets Context.asdevice() recognise a host array whose bytes are already on the device and return the device
+    array that is still alive instead.  An entry is only ever made for memory that CANNOT have changed since:
 
       * key: address, shape, strides and dtype of the host array (C-contiguous arrays of at least MIN_BYTES only);
       * liveness: a weak reference to the object that owns the memory (the end of the array's .base chain); when it
         dies the entry goes with it, so a recycled address can never match;
-      * write guard: a CRC of head, tail and SAMPLES evenly strided bytes of the array, taken when the pair is
-        recorded and checked on every hit.  Whole-array and block updates change it; an edit of a few isolated
-        elements can escape it.  MICROALIGNER_RESIDENT=readonly hands results out read-only instead (a hard guarantee:
-        writes raise), MICROALIGNER_RESIDENT=off disables the cache;
+      * immutability (mode "results", the default): the arrays DeviceArray.numpy() hands out -- the flow of register(),
+        the image of warp() -- are marked read-only down to the root of their base chain, so an in-place edit raises
+        (numpy: "assignment destination is read-only") instead of going unnoticed; take a .copy() to edit one.  Arrays
+        of the caller are recorded only when they are read-only themselves (np.memmap(mode="r"), arr.flags.writeable =
+        False on the owner).  A hit requires every array of the base chain to be read-only still;
       * bound: least recently used pairs are dropped beyond MICROALIGNER_RESIDENT_GB (default 16) of device memory.
+
+    MICROALIGNER_RESIDENT=off: no cache, results are ordinary writable arrays (everything is uploaded every time).
+    MICROALIGNER_RESIDENT=sampled: results stay writable and ANY uploaded array is recorded, guarded by a CRC of head,
+    tail and SAMPLES strided bytes checked on every hit -- cheap, but NOT sound: an in-place edit of a block that falls
+    between the samples (stride ~256 KiB at 2 GB) goes unnoticed and the stale device copy is used.  Opt-in only, for
+    callers that never edit arrays in place.
 
     Device arrays are never modified in place (every operation allocates its output), so a recorded pair stays valid
     for as long as the host side is untouched."""
@@ -140,13 +150,18 @@ class _ResidentCache:
     EDGE = 4096
 
     def __init__(self):
-        self.mode = os.environ.get("MICROALIGNER_RESIDENT", "sampled").lower()
-        if self.mode not in ("sampled", "readonly", "off"):
-            raise ValueError("MICROALIGNER_RESIDENT must be one of sampled, readonly, off")
+        self.mode = os.environ.get("MICROALIGNER_RESIDENT", "results").lower()
+        if self.mode == "readonly":      # earlier name of the default mode
+            self.mode = "results"
+        if self.mode not in ("results", "sampled", "off"):
+            raise ValueError("MICROALIGNER_RESIDENT must be one of results, sampled, off")
         self.limit = int(float(os.environ.get("MICROALIGNER_RESIDENT_GB", "16")) * (1 << 30))
         self.entries = collections.OrderedDict()   # key -> [weakref(owner), DeviceArray, signature]
         self.bytes = 0
         self.hits = 0
+        # weak-reference callbacks (_forget) run from the collector on whichever thread it picks, and the engines of
+        # parallel.stream_pairs run on their own threads; re-entrant: a callback can fire inside remember() / lookup()
+        self.lock = threading.RLock()
 
     @staticmethod
     def _key(arr):
@@ -158,6 +173,23 @@ class _ResidentCache:
             arr = arr.base
         return arr.base if getattr(arr, "base", None) is not None else arr
 
+    @staticmethod
+    def _frozen(arr):
+        """True when neither `arr` nor any array it is a view of can be written through numpy."""
+        while isinstance(arr, np.ndarray):
+            if arr.flags.writeable:
+                return False
+            arr = arr.base
+        return True
+
+    @staticmethod
+    def freeze(arr):
+        """Mark `arr` and every array of its base chain read-only (root first is not needed: clearing the flag is
+        always allowed; setting it again is refused by numpy while the root is read-only)."""
+        while isinstance(arr, np.ndarray):
+            arr.flags.writeable = False
+            arr = arr.base
+
     @classmethod
     def _signature(cls, arr):
         b = arr.reshape(-1).view(np.uint8)
@@ -168,8 +200,10 @@ class _ResidentCache:
         return zlib.crc32(b[::step].tobytes(), crc)
 
     def _eligible(self, arr):
-        return (self.mode != "off" and isinstance(arr, np.ndarray) and arr.flags.c_contiguous
-                and arr.nbytes >= self.MIN_BYTES)
+        if not (self.mode != "off" and isinstance(arr, np.ndarray) and arr.flags.c_contiguous
+                and arr.nbytes >= self.MIN_BYTES):
+            return False
+        return self.mode == "sampled" or self._frozen(arr)
 
     def remember(self, arr, dev):
         if not self._eligible(arr) or dev.ptr is None:
@@ -179,35 +213,43 @@ class _ResidentCache:
             ref = weakref.ref(self._owner(arr), lambda _r, k=key: self._forget(k))
         except TypeError:       # the memory owner cannot be weakly referenced (mmap, bytes): liveness unknown
             return
-        self._forget(key)
-        self.entries[key] = [ref, dev, self._signature(arr)]
-        self.bytes += dev.nbytes
-        while self.bytes > self.limit and len(self.entries) > 1:
-            self._forget(next(iter(self.entries)))
+        sig = self._signature(arr) if self.mode == "sampled" else None
+        with self.lock:
+            self._forget(key)
+            self.entries[key] = [ref, dev, sig]
+            self.bytes += dev.nbytes
+            while self.bytes > self.limit and len(self.entries) > 1:
+                self._forget(next(iter(self.entries)))
 
     def _forget(self, key):
-        e = self.entries.pop(key, None)
-        if e is not None:
-            self.bytes -= e[1].nbytes if e[1].ptr is not None else 0
+        with self.lock:
+            e = self.entries.pop(key, None)
+            if e is not None:
+                self.bytes -= e[1].nbytes if e[1].ptr is not None else 0
 
     def lookup(self, arr):
-        if not self._eligible(arr):
+        if not self._eligible(arr):     # results mode: an array that has become writable again is never a hit
+            if self.mode != "off" and isinstance(arr, np.ndarray):
+                self._forget(self._key(arr))
             return None
         key = self._key(arr)
-        e = self.entries.get(key)
-        if e is None:
-            return None
-        ref, dev, sig = e
-        if ref() is None or dev.ptr is None or dev.shape != arr.shape or dev.dtype != arr.dtype or self._signature(arr) != sig:
-            self._forget(key)
-            return None
-        self.entries.move_to_end(key)
-        self.hits += 1
-        return dev
+        with self.lock:
+            e = self.entries.get(key)
+            if e is None:
+                return None
+            ref, dev, sig = e
+            if (ref() is None or dev.ptr is None or dev.shape != arr.shape or dev.dtype != arr.dtype
+                    or (sig is not None and self._signature(arr) != sig)):
+                self._forget(key)
+                return None
+            self.entries.move_to_end(key)
+            self.hits += 1
+            return dev
 
     def clear(self):
-        self.entries.clear()
-        self.bytes = 0
+        with self.lock:
+            self.entries.clear()
+            self.bytes = 0
 
 
 class Context:
@@ -314,8 +356,9 @@ class Context:
     # this number, a loop that drops each result before the next but one reuses the same two buffers forever.
     HOST_PINNED_PER_BUCKET = 2
 
-    def host_empty(self, shape, dtype):
-        """ndarray on page-locked host memory drawn from a pool.  The memory returns to the pool when the array
+    def host_empty(self, shape, dtype, limit=None):
+        """ndarray on page-locked host memory drawn from a pool (`limit`: page-locked buffers of this size the context
+        may own, default HOST_PINNED_PER_BUCKET; parallel.stream_pairs keeps more results in flight).  The memory returns to the pool when the array
         and all views of it are gone (the array's base object is the owner), so a loop that keeps calling
         register() / warp() reuses the same already-faulted, DMA-able buffers instead of paying a page fault per
         4 KiB of every fresh result."""
@@ -329,7 +372,7 @@ class Context:
             free = self._host_pool.get(bucket)
             ptr = free.pop() if free else None
             if ptr is None:
-                if self._host_owned.get(bucket, 0) >= self.HOST_PINNED_PER_BUCKET:
+                if self._host_owned.get(bucket, 0) >= (limit or self.HOST_PINNED_PER_BUCKET):
                     return np.empty(shape, dtype)
                 self._host_owned[bucket] = self._host_owned.get(bucket, 0) + 1
         if ptr is None:
@@ -343,6 +386,13 @@ class Context:
         owner = _HostBuffer(self, ptr, bucket, nbytes)
         return np.asarray(owner).view(dtype).reshape(shape)   # base chain ends at `owner`
 
+    def host_reserve(self, shape, dtype, count):
+        """Make sure the pool can hand out `count` page-locked arrays of this shape at once (allocating what is missing
+        now, in one go: hipHostMalloc takes ~0.2 s per GiB and stalls other HIP calls of the process while it runs, so a
+        pipeline does this before its first pair rather than in the middle of the stream)."""
+        held = [self.host_empty(shape, dtype, limit=count) for _ in range(count)]
+        del held
+
     def _host_release(self, ptr, bucket):
         with self._host_lock:
             if not self._closed:
@@ -352,6 +402,53 @@ class Context:
 
     def sync(self):
         L.check(self.lib.ma_sync(self.handle))
+
+    # -- options / transfer engines ------------------------------------------------------------
+    def set_option(self, option, value):
+        L.check(self.lib.ma_ctx_set_option(self.handle, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_longlong()
+        L.check(self.lib.ma_ctx_get_option(self.handle, int(option), C.byref(v)))
+        return v.value
+
+    @property
+    def companion_stream(self):
+        """Whether ma_optflow_register runs the flow-independent dog() calls on the low-priority companion stream
+        (MA_OPT_COMPANION_STREAM, default True).  False: one stream, every kernel alone on the chip (profiling)."""
+        return bool(self.get_option(L.MA_OPT_COMPANION_STREAM))
+
+    @companion_stream.setter
+    def companion_stream(self, on):
+        self.set_option(L.MA_OPT_COMPANION_STREAM, 1 if on else 0)
+
+    def engine_upload(self, dst, arr, engine=L.MA_ENGINE_H2D):
+        """Copy the C-contiguous host array `arr` into the DeviceArray `dst` on a transfer engine's stream; returns when
+        this copy is complete (the compute stream is not involved: order it with engine_record / engine_wait)."""
+        if arr.nbytes != dst.nbytes or not arr.flags.c_contiguous:
+            raise ValueError("engine_upload needs a C-contiguous host array of the device array's size")
+        L.check(self.lib.ma_engine_memcpy_h2d(self.handle, int(engine), dst.ptr, arr.ctypes.data, arr.nbytes))
+
+    def engine_download(self, src, out, engine=L.MA_ENGINE_D2H):
+        if out.nbytes != src.nbytes or not out.flags.c_contiguous:
+            raise ValueError("engine_download needs a C-contiguous host array of the device array's size")
+        L.check(self.lib.ma_engine_memcpy_d2h(self.handle, int(engine), out.ctypes.data, src.ptr, out.nbytes))
+
+    def engine_record(self, engine, ev):
+        L.check(self.lib.ma_engine_record(self.handle, int(engine), ev))
+
+    def engine_wait(self, engine, ev):
+        L.check(self.lib.ma_engine_wait(self.handle, int(engine), ev))
+
+    def engine_sync(self, engine):
+        L.check(self.lib.ma_engine_sync(self.handle, int(engine)))
+
+    def event_sync(self, ev):
+        L.check(self.lib.ma_event_sync(self.handle, ev))
+
+    def event_destroy(self, ev):
+        if not self._closed:
+            self.lib.ma_event_destroy(self.handle, ev)
 
     def clock_probe(self, milliseconds=20.0):
         """Sustained shader clock in GHz under a packed-FP32 load (ma_clock_probe)."""
@@ -759,6 +856,61 @@ def get_context(device=None):
                                  "(MICROALIGNER_DEVICE / LOCAL_RANK select the device of this process)")
             ctx = _contexts[device] = Context(device)
     return ctx
+
+
+def _parse_cpulist(text):
+    """"0-63,128-191" -> sorted list of CPU indices (the format of sysfs cpulist files)."""
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def device_local_cpus(device=0, pci_bus_id=None, sysfs="/sys/bus/pci/devices"):
+    """CPUs of the NUMA node a device hangs off (/sys/bus/pci/devices/<bdf>/local_cpulist), [] when unknown."""
+    try:
+        bdf = (pci_bus_id or device_info(device)["pci_bus_id"]).lower()
+        with open(os.path.join(sysfs, bdf, "local_cpulist")) as f:
+            return _parse_cpulist(f.read())
+    except (OSError, ValueError, RuntimeError, KeyError):
+        return []
+
+
+def bind_to_device_numa(device=None, pci_bus_id=None, sysfs="/sys/bus/pci/devices"):
+    """Pin this process (and every thread it starts afterwards) to the CPUs next to its GPU, so that the page-locked
+    transfer buffers it allocates from now on and the pages its loaders first touch are on the memory the GPU reaches
+    without crossing the socket interconnect: on a two-socket host a remote buffer costs a third of the PCIe rate
+    (profiles/r04_notes.md).  One process per GPU: call it first thing in a rank.  Returns the CPU list it
+    applied ([] when the topology is unknown or MICROALIGNER_BIND_NUMA=0: nothing changed); the previous mask is returned
+    by os.sched_getaffinity before the call if the caller wants to restore it."""
+    if os.environ.get("MICROALIGNER_BIND_NUMA", "1") == "0":
+        return []
+    cpus = device_local_cpus(default_device() if device is None else device, pci_bus_id, sysfs)
+    allowed = os.sched_getaffinity(0)
+    cpus = [c for c in cpus if c in allowed]
+    if not cpus or set(cpus) == set(allowed):
+        return []
+    set_affinity(cpus)
+    return cpus
+
+
+def set_affinity(cpus):
+    """Affinity of EVERY thread of this process (sched_setaffinity(0, ...) alone moves the calling thread only; the HIP
+    runtime's helper threads, which carry the staged copies, exist already once a device has been queried)."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        tids = [0]
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except OSError:
+            pass        # a thread that exited in the meantime
+    os.sched_setaffinity(0, cpus)
 
 
 def device_count():

@@ -106,25 +106,272 @@ def run_sharded(units: Sequence, fn: Callable, gather: bool = True, dst: int = 0
     rank, ws = world()
     mine = shard(len(units), rank, ws)
     local = _run_local(units, mine, fn, lanes)
-    if not gather:
-        return local
-    if ws == 1:
-        return [local[i] for i in range(len(units))]
-    import torch.distributed as dist
-    bucket: Optional[list] = [None] * ws if rank == dst else None
-    dist.gather_object(local, bucket, dst=dst)
-    if rank != dst:
-        return None
-    merged = {}
-    for part in bucket:
-        merged.update(part)
-    return [merged[i] for i in range(len(units))]
+    return _gather(local, len(units), gather, dst)
+
+
+class PairResult:
+    """What stream_pairs yields per pair: the host arrays, the per-level reports and the pair's position in the input."""
+
+    __slots__ = ("index", "flow", "warped", "reports", "extra")
+
+    def __init__(self, index, flow, warped, reports, extra=None):
+        self.index, self.flow, self.warped, self.reports, self.extra = index, flow, warped, reports, extra
+
+    def __iter__(self):          # `flow, warped = result`
+        return iter((self.flow, self.warped))
+
+
+def _optflow_stage(params, warp):
+    """The compute stage of stream_pairs: register() (+ warp()) on device arrays -> (device results, reports, extra)."""
+    from . import OptFlowRegistrator
+
+    def stage(ctx, dref, dmov):
+        reg = OptFlowRegistrator()
+        reg.verbose = False
+        for k, v in params.items():
+            setattr(reg, k, v)
+        reg.ref_img, reg.mov_img = dref, dmov
+        flow = reg.register()
+        warped = ctx.warp(dmov, flow, reg.tile_size, reg.overlap) if warp else None
+        return [flow, warped], reg.level_reports, None
+
+    return stage
+
+
+def stream_pairs(pairs, params: Optional[dict] = None, warp: bool = True, depth: int = 2, stats: Optional[dict] = None,
+                 stage: Optional[Callable] = None, out: Optional[Callable] = None):
+    """Register a STREAM of (ref, mov) host pairs on this process's GPU, numpy in -> numpy out, with the upload of
+    pair k+1 and the download of pair k-1 hidden behind the kernels of pair k.
+
+    The reference meets its inputs one page at a time (TIFF pages read in __main__.py:398-433, "one page in memory",
+    README.md:5) and overlaps work through dask (flow_calc.py:88-98, utils.py:117-123).  Here ONE context drives three
+    engines (include/microaligner_hip.h, "transfer engines"), each from its own persistent host thread:
+
+      upload   : pulls the next pair from `pairs` (any iterable, evaluated lazily and on this thread: a generator that
+                 reads files overlaps too), copies it into a free device input slot on the H2D stream, records an event;
+      compute  : waits for that event on the compute stream, runs OptFlowRegistrator.register() and Warper.warp() on
+                 the device arrays (the C engine, ma_optflow_register), records an event;
+      download : waits for that event on the D2H stream, copies flow and warped image into page-locked host arrays
+                 (the context's pool; pageable beyond its limit), hands the input slot back and yields.
+
+    Events order the engines on the device; the host threads never wait for each other's copies.  Every byte crosses the
+    bus once (ma_ctx_transfer_stats).  Results come out in input order as PairResult(index, flow, warped, reports);
+    `for flow, warped in stream_pairs(...)` works too.  `depth`: pairs that may wait between two engines (device memory:
+    depth + 1 input slots, result buffers of up to depth + 1 pairs).  `stats`, if given, receives the busy time of each
+    engine, the wall time and the byte counts when the stream ends.  `out`: optional callable index -> (flow_out,
+    warped_out) host arrays to fill instead of pool arrays (e.g. rows of a memmap; either may be None).
+    `stage`: replaces the compute step (align_pairs uses it): callable (ctx, dref, dmov) -> ([device arrays to
+    download], reports, extra).  Bit-identical to the one-pair path: same kernels on the same inputs."""
+    import queue
+    import threading
+    import time
+
+    import numpy as np
+
+    from . import _lib as L
+    from .device import _dt, get_context, use_context
+
+    ctx = get_context()
+    params = dict(params or {})
+    if depth < 1:
+        raise ValueError("depth must be >= 1")
+    stage = stage or _optflow_stage(params, warp)
+    n_slots = depth + 1
+    # host result arrays alive at once: one being filled, one queued, one just yielded, one the consumer still names
+    n_results = depth + 2
+    q_up, q_done, q_out = queue.Queue(depth), queue.Queue(depth), queue.Queue(1)
+    q_free = queue.Queue()
+    stop = threading.Event()
+    errors: list = []
+    busy = {"h2d_busy_ms": 0.0, "d2h_busy_ms": 0.0, "compute_busy_ms": 0.0, "pairs": 0}
+    reserved = set()
+    timeline = {}                  # pair index -> host-side time stamps (seconds since the stream started) per engine
+    END = object()
+
+    def put(q, item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def get(q):
+        while not stop.is_set():
+            try:
+                return q.get(timeout=0.1)
+            except queue.Empty:
+                pass
+        return END
+
+    def fail(e):
+        errors.append(e)
+        stop.set()
+
+    ctx.sync()                     # everything enqueued so far is complete: any pooled buffer may be written by any engine
+    up0, down0 = ctx.transfer_stats()
+
+    class Slot:
+        def __init__(self):
+            self.ref = self.mov = None
+            self.ev_up, self.ev_start, self.ev_done = ctx.event(), ctx.event(), ctx.event()
+
+    slots = [Slot() for _ in range(n_slots)]
+
+    def uploader():
+        try:
+            in_flight_shape = None
+            for index, pair in enumerate(pairs):
+                if stop.is_set():
+                    return
+                ref, mov = pair
+                ref, mov = np.ascontiguousarray(ref), np.ascontiguousarray(mov)
+                _dt(ref.dtype), _dt(mov.dtype)
+                if ref.ndim != 2 or mov.ndim != 2:
+                    raise ValueError(f"pair {index}: images must be 2-D, got {ref.shape} and {mov.shape}")
+                key = (ref.shape, ref.dtype, mov.shape, mov.dtype)
+                if key != in_flight_shape:
+                    # (re)size the input slots: only when nothing is in flight, so that no engine can still be using a
+                    # buffer the pool hands out (first pair: the pipeline is empty by construction)
+                    have = []
+                    while len(have) < n_slots:
+                        s = get(q_free) if in_flight_shape is not None else slots[len(have)]
+                        if s is END:
+                            return
+                        have.append(s)
+                    for s in have:
+                        s.ref = s.mov = None
+                    if in_flight_shape is not None:
+                        ctx.sync()
+                    for s in have:
+                        s.ref, s.mov = ctx.empty(ref.shape, ref.dtype), ctx.empty(mov.shape, mov.dtype)
+                        q_free.put(s)
+                    in_flight_shape = key
+                slot = get(q_free)
+                if slot is END:
+                    return
+                t0 = time.perf_counter()
+                ctx.engine_upload(slot.ref, ref)
+                ctx.engine_upload(slot.mov, mov)
+                t1 = time.perf_counter()
+                busy["h2d_busy_ms"] += (t1 - t0) * 1e3
+                timeline[index] = {"h2d": (t0 - t_wall, t1 - t_wall)}
+                ctx.engine_record(L.MA_ENGINE_H2D, slot.ev_up)
+                if not put(q_up, (index, slot)):
+                    return
+            put(q_up, END)
+        except BaseException as e:
+            fail(e)
+
+    def computer():
+        try:
+            with use_context(ctx):
+                while True:
+                    item = get(q_up)
+                    if item is END:
+                        break
+                    index, slot = item
+                    t0 = time.perf_counter()
+                    ctx.engine_wait(L.MA_ENGINE_COMPUTE, slot.ev_up)
+                    ctx.engine_record(L.MA_ENGINE_COMPUTE, slot.ev_start)
+                    devs, reports, extra = stage(ctx, slot.ref, slot.mov)
+                    ctx.engine_record(L.MA_ENGINE_COMPUTE, slot.ev_done)
+                    timeline[index]["compute_host"] = (t0 - t_wall, time.perf_counter() - t_wall)
+                    if not put(q_done, (index, slot, devs, reports, extra)):
+                        return
+            put(q_done, END)
+        except BaseException as e:
+            fail(e)
+
+    def downloader():
+        try:
+            while True:
+                item = get(q_done)
+                if item is END:
+                    break
+                index, slot, devs, reports, extra = item
+                ctx.engine_wait(L.MA_ENGINE_D2H, slot.ev_done)
+                ctx.event_sync(slot.ev_done)               # the wait for the kernels is not transfer time
+                t_done = time.perf_counter()
+                gpu_ms = ctx.elapsed_ms(slot.ev_start, slot.ev_done)
+                busy["compute_busy_ms"] += gpu_ms
+                timeline[index]["compute_gpu_ms"] = gpu_ms
+                timeline[index]["compute_done"] = t_done - t_wall
+                put(q_free, slot)                          # the inputs are no longer read: the slot can be refilled
+                targets = list(out(index)) if out is not None else [None] * len(devs)
+                if len(targets) != len(devs):
+                    raise ValueError(f"out({index}) must return {len(devs)} arrays (or None entries)")
+                hosts = []
+                t_busy = 0.0
+                for k, (d, tgt) in enumerate(zip(devs, targets)):
+                    if d is None:
+                        hosts.append(None)
+                        continue
+                    if tgt is None:
+                        if (d.shape, d.dtype) not in reserved and out is None:
+                            ctx.host_reserve(d.shape, d.dtype, n_results)     # once per result shape, before its first copy
+                            reserved.add((d.shape, d.dtype))
+                        tgt = ctx.host_empty(d.shape, d.dtype, limit=n_results)
+                    elif (tuple(tgt.shape) != d.shape or tgt.dtype != d.dtype or not tgt.flags.c_contiguous
+                          or not tgt.flags.writeable):
+                        raise ValueError(f"pair {index}: output {k} must be a writable C-contiguous {d.dtype} array of "
+                                         f"shape {d.shape}")
+                    t0 = time.perf_counter()
+                    ctx.engine_download(d, tgt)
+                    t_busy += time.perf_counter() - t0
+                    hosts.append(tgt)
+                busy["d2h_busy_ms"] += t_busy * 1e3
+                busy["pairs"] += 1
+                timeline[index]["d2h"] = (time.perf_counter() - t_wall - t_busy, time.perf_counter() - t_wall)
+                del devs, item                             # device results go back to the pool: their copies are complete
+                if not put(q_out, PairResult(index, hosts[0], hosts[1] if len(hosts) > 1 else None, reports, extra)):
+                    return
+            put(q_out, END)
+        except BaseException as e:
+            fail(e)
+
+    threads = [threading.Thread(target=f, name=f"ma-engine-{n}", daemon=True)
+               for n, f in (("h2d", uploader), ("compute", computer), ("d2h", downloader))]
+    t_wall = time.perf_counter()
+    for t in threads:
+        t.start()
+    try:
+        while True:
+            res = get(q_out)
+            if res is END:
+                break
+            yield res
+            res = None
+        if errors:
+            raise errors[0]
+    finally:
+        stop.set()
+        for t in threads:
+            t.join()
+        try:
+            ctx.sync()
+            for e in (L.MA_ENGINE_H2D, L.MA_ENGINE_D2H):
+                ctx.engine_sync(e)
+        finally:
+            for s in slots:
+                s.ref = s.mov = None
+                for ev in (s.ev_up, s.ev_start, s.ev_done):
+                    ctx.event_destroy(ev)
+        if stats is not None:
+            up1, down1 = ctx.transfer_stats()
+            stats.update(busy, wall_ms=(time.perf_counter() - t_wall) * 1e3, h2d_bytes=up1 - up0, d2h_bytes=down1 - down0,
+                         depth=depth, timeline=[timeline[i] for i in sorted(timeline)])
 
 
 def register_pairs(pairs: Sequence, params: Optional[dict] = None, warp: bool = False, gather: bool = True,
-                   lanes: int = 1):
-    """Register every (ref, mov) pair of `pairs` on this rank's GPU share, `lanes` pairs in flight per GPU.
-    Returns flows (and warped moving images if warp=True) as numpy arrays, in pair order on rank 0."""
+                   lanes: int = 1, stream: Optional[bool] = None):
+    """Register every (ref, mov) pair of `pairs` on this rank's GPU share.  Returns flows (and warped moving images if
+    warp=True) as numpy arrays, in pair order on rank 0.
+    stream (default: on for host arrays when lanes == 1): the rank's share goes through stream_pairs -- one context,
+    transfers overlapped with the kernels -- instead of one blocking upload / compute / download per pair.
+    lanes > 1: the older scheme, `lanes` host threads each with a context of their own."""
+    import numpy as np
     from . import OptFlowRegistrator, Warper
     params = dict(params or {})
 
@@ -143,7 +390,37 @@ def register_pairs(pairs: Sequence, params: Optional[dict] = None, warp: bool = 
         w.image, w.flow = mov, flow
         return flow, w.warp()
 
-    return run_sharded(pairs, one, gather=gather, lanes=lanes)
+    rank, ws = world()
+    mine = shard(len(pairs), rank, ws)
+    host_in = all(isinstance(pairs[i][0], np.ndarray) and isinstance(pairs[i][1], np.ndarray) for i in mine)
+    if stream is None:
+        stream = lanes <= 1 and host_in and len(mine) > 1
+    if not stream:
+        return run_sharded(pairs, one, gather=gather, lanes=lanes)
+    if not host_in:
+        raise ValueError("stream=True needs host (numpy) pairs")
+    local = {}
+    for res in stream_pairs((pairs[i] for i in mine), params, warp=warp):
+        local[mine[res.index]] = (res.flow, res.warped) if warp else res.flow
+    return _gather(local, len(pairs), gather)
+
+
+def _gather(local: dict, n_units: int, gather: bool, dst: int = 0):
+    """{unit index: result} of this rank -> the full list in unit order on rank `dst` (None elsewhere)."""
+    rank, ws = world()
+    if not gather:
+        return local
+    if ws == 1:
+        return [local[i] for i in range(n_units)]
+    import torch.distributed as dist
+    bucket: Optional[list] = [None] * ws if rank == dst else None
+    dist.gather_object(local, bucket, dst=dst)
+    if rank != dst:
+        return None
+    merged = {}
+    for part in bucket:
+        merged.update(part)
+    return [merged[i] for i in range(n_units)]
 
 
 def warp_pages(pages: Sequence, flow, tile_size: int = 1000, overlap: int = 100, gather: bool = True):

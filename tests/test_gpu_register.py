@@ -388,7 +388,10 @@ def test_reference_shaped_numpy_loop_uploads_nothing_twice(ctx):
     reg = make_reg(params)
     reg.ref_img, reg.mov_img = ref, mov
     flow = reg.register()
-    assert isinstance(flow, np.ndarray) and flow.flags.writeable
+    # results are handed out read-only (that is what makes recognising them sound): an in-place edit raises
+    assert isinstance(flow, np.ndarray) and not flow.flags.writeable
+    with pytest.raises(ValueError, match="read-only"):
+        flow[10:20, 10:20] = 0
     w = Warper()
     w.tile_size, w.overlap = 200, 40
     w.image, w.flow = mov, flow                     # __main__.py:421-424
@@ -400,32 +403,46 @@ def test_reference_shaped_numpy_loop_uploads_nothing_twice(ctx):
         out.append(w.warp())
     up, down = ctx.transfer_stats()
     page_bytes = sum(p.nbytes for p in pages)
-    assert up == ref.nbytes + mov.nbytes + page_bytes, f"uploaded {up} bytes"
+    # the flow is never uploaded; the caller's WRITABLE mov array cannot be trusted to be unchanged and goes up twice
+    assert up == ref.nbytes + 2 * mov.nbytes + page_bytes, f"uploaded {up} bytes"
     assert down == flow.nbytes + warped.nbytes + page_bytes
     exp_flow, _ = RO.register(ref, mov, **params)
     assert np.array_equal(flow, exp_flow) and np.array_equal(warped, RO.warp(mov, exp_flow, 200, 40))
     for p, o in zip(pages, out):
         assert o.dtype == np.uint16 and np.array_equal(o, RO.warp(p, exp_flow, 200, 40))
-    # an edited flow is noticed (the sampled write guard) and uploaded again; so is a new array at a recycled address
-    flow *= 0.5
+    # a caller that marks its inputs read-only gets them recognised as well: mov goes up once
+    ctx.forget_host_arrays()
     ctx.transfer_stats(reset=True)
-    w.image, w.flow = pages[0], flow
+    ref.flags.writeable = mov.flags.writeable = False
+    reg.ref_img, reg.mov_img = ref, mov
+    flow2 = reg.register()
+    w.image, w.flow = mov, flow2
+    warped2 = w.warp()
+    assert ctx.transfer_stats()[0] == ref.nbytes + mov.nbytes
+    assert np.array_equal(flow2, exp_flow) and np.array_equal(warped2, warped)
+    # an edited COPY of the flow is a new array: uploaded, and the result follows the edit (the advisor's scenario:
+    # flow[y0:y1, x0:x1] = 0 between register() and warp() can no longer pick up a stale device copy)
+    edited = flow.copy()
+    edited[100:200, 100:200] = 0
+    ctx.transfer_stats(reset=True)
+    w.image, w.flow = pages[0], edited
     again = w.warp()
-    assert ctx.transfer_stats()[0] == flow.nbytes + pages[0].nbytes
-    assert np.array_equal(again, RO.warp(pages[0], flow, 200, 40))
+    assert ctx.transfer_stats()[0] == edited.nbytes + pages[0].nbytes
+    assert np.array_equal(again, RO.warp(pages[0], edited, 200, 40))
     n_before = len(ctx._resident.entries)
-    del flow, exp_flow, w
+    del flow, flow2, exp_flow, w
     import gc
     gc.collect()
     assert len(ctx._resident.entries) < n_before      # the pair dies with the host array
 
 
 def test_resident_cache_modes(monkeypatch):
-    """MICROALIGNER_RESIDENT=readonly hands results out read-only (the hard write guard); =off uploads every time."""
+    """MICROALIGNER_RESIDENT: results (default; read-only results are recognised, writable caller arrays are not), off
+    (everything uploaded every time, writable results), sampled (opt-in, the unsound CRC guard of round 3)."""
     from microaligner_amd.device import Context, use_context
     img, _ = synthetic.make_pair(600, 600, seed=3)
     flow = np.full((600, 600, 2), 1.5, np.float32)
-    for mode, uploads in (("readonly", 1), ("off", 2), ("sampled", 1)):
+    for mode, uploads, writable in (("results", 2, False), ("readonly", 2, False), ("off", 2, True), ("sampled", 1, True)):
         monkeypatch.setenv("MICROALIGNER_RESIDENT", mode)
         c = Context(0)
         try:
@@ -434,14 +451,94 @@ def test_resident_cache_modes(monkeypatch):
                 for _ in range(2):
                     w.image, w.flow = img, flow
                     res = w.warp()
-                assert c.transfer_stats()[0] == uploads * (img.nbytes + flow.nbytes)
-                assert res.flags.writeable == (mode != "readonly")
+                assert c.transfer_stats()[0] == uploads * (img.nbytes + flow.nbytes), mode
+                assert res.flags.writeable == writable
                 assert np.array_equal(res, RO.warp(img, flow, 1000, 100))
+                # a result handed back in: recognised in "results" (and "sampled"), uploaded in "off"
+                c.transfer_stats(reset=True)
+                w.image, w.flow = res, flow
+                w.warp()
+                assert c.transfer_stats()[0] == flow.nbytes * (mode != "sampled") + res.nbytes * (mode == "off"), mode
+                # a caller's `out` array is filled but its flags are never touched
+                mine = np.empty((600, 600), np.float32)
+                c.asdevice(img).numpy(out=mine)
+                assert mine.flags.writeable and np.array_equal(mine, img)
         finally:
             c.close()
     monkeypatch.setenv("MICROALIGNER_RESIDENT", "sometimes")
     with pytest.raises(ValueError):
         Context(0)
+
+
+def test_stream_pairs_equals_the_one_pair_path_and_moves_every_byte_once(ctx):
+    """parallel.stream_pairs (three engines of one context: upload of pair k+1 and download of pair k-1 under the kernels
+    of pair k) against register() + warp() pair by pair: flows, warped images and per-level reports identical, results in
+    input order, every byte crosses the bus exactly once (ma_ctx_transfer_stats), shapes and dtypes may change
+    mid-stream, and the results are the oracle's."""
+    from microaligner_amd import parallel
+    params = dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True, tile_size=300, overlap=40)
+    specs = [((700, 900), np.float32)] * 4 + [((640, 520), np.uint8)] * 3 + [((700, 900), np.float32)] * 2
+    pairs = [synthetic.make_pair(h, w, 40 + k, dt) for k, ((h, w), dt) in enumerate(specs)]
+    single = []
+    for ref, mov in pairs:
+        reg = make_reg(params)
+        reg.ref_img, reg.mov_img = ref, mov
+        flow = reg.register()
+        w = Warper()
+        w.tile_size, w.overlap = 300, 40
+        w.image, w.flow = mov, flow
+        single.append((flow, w.warp(), [(r.factor, r.mi_after, r.mi_before, r.accepted) for r in reg.level_reports]))
+    ctx.forget_host_arrays()
+    stats = {}
+    got = list(parallel.stream_pairs(iter(pairs), params, warp=True, stats=stats))
+    assert [r.index for r in got] == list(range(len(pairs)))
+    for r, (flow, warped, reports) in zip(got, single):
+        assert np.array_equal(r.flow, flow) and np.array_equal(r.warped, warped)
+        assert [(x.factor, x.mi_after, x.mi_before, x.accepted) for x in r.reports] == reports
+        assert r.flow.flags.writeable                     # stream results are plain arrays: nothing is cached behind them
+    assert stats["h2d_bytes"] == sum(a.nbytes + b.nbytes for a, b in pairs)
+    assert stats["d2h_bytes"] == sum(f.nbytes + w_.nbytes for f, w_, _ in single)
+    assert stats["pairs"] == len(pairs) and min(stats[k] for k in ("h2d_busy_ms", "compute_busy_ms", "d2h_busy_ms")) > 0
+    exp_flow, _ = RO.register(*pairs[5], **params)
+    assert np.array_equal(got[5].flow, exp_flow) and np.array_equal(got[5].warped, RO.warp(pairs[5][1], exp_flow, 300, 40))
+    # flows only, into caller-provided rows (a memmap in the pipeline)
+    dst = np.zeros((4, 700, 900, 2), np.float32)
+    for r in parallel.stream_pairs(pairs[:4], params, warp=False, out=lambda i: (dst[i], None)):
+        assert r.warped is None
+    assert all(np.array_equal(dst[i], single[i][0]) for i in range(4))
+    # register_pairs routes host pairs through the stream
+    flows = parallel.register_pairs(pairs[:4], params, warp=True)
+    assert all(np.array_equal(f, single[i][0]) and np.array_equal(w_, single[i][1]) for i, (f, w_) in enumerate(flows))
+
+
+def test_companion_stream_switch_changes_nothing_but_the_schedule(ctx):
+    """MA_OPT_COMPANION_STREAM off (every kernel alone on the chip, for profiles) and on: same flow, same reports,
+    through the C engine; the option reads back; unknown options are rejected."""
+    from microaligner_amd import _lib as L
+    params = dict(num_pyr_lvl=3, use_full_res_img=True, use_dog=True, tile_size=200, overlap=40)
+    ref, mov = synthetic.make_pair(900, 1100, seed=8)
+    dref, dmov = ctx.asdevice(ref), ctx.asdevice(mov)
+    out = {}
+    assert ctx.companion_stream is True
+    try:
+        for on in (True, False, True):
+            ctx.companion_stream = on
+            assert ctx.companion_stream is on
+            reg = make_reg(params)
+            reg.ref_img, reg.mov_img = dref, dmov
+            flow = reg.register().numpy()
+            out.setdefault(on, []).append((flow, [(r.factor, r.shape, r.mi_after, r.mi_before, r.accepted)
+                                                  for r in reg.level_reports]))
+    finally:
+        ctx.companion_stream = True
+    base_flow, base_rep = out[True][0]
+    for flow, rep in out[True][1:] + out[False]:
+        assert np.array_equal(flow, base_flow) and rep == base_rep
+    exp, _ = RO.register(ref, mov, **params)
+    assert np.array_equal(base_flow, exp)
+    with pytest.raises(ValueError):
+        ctx.set_option(99, 1)
+    assert ctx.get_option(L.MA_OPT_WORKSPACE_LIMIT) > 0
 
 
 def test_register_pairs_with_lanes_matches_single_lane():

@@ -124,43 +124,237 @@ def test_lanes_run_every_unit_once_under_their_own_context(monkeypatch):
         parallel.run_sharded(list(range(8)), bad, lanes=2)
 
 
-def test_resident_cache_recognises_unmodified_host_arrays_only():
-    """The host <-> device pair cache behind Context.asdevice() (no device needed: a stand-in device array): same memory
-    and same bytes hit, edits and recycled or dead memory miss, small arrays are never recorded, the byte bound evicts
-    the least recently used pair."""
+class _Dev:
+    def __init__(self, a):
+        self.ptr, self.shape, self.dtype, self.nbytes = 1, a.shape, a.dtype, a.nbytes
+
+
+def test_resident_cache_only_trusts_memory_that_cannot_change(monkeypatch):
+    """The host <-> device pair cache behind Context.asdevice() (no device needed: a stand-in device array).  Default
+    mode "results": only read-only memory is ever recorded -- the arrays the library hands out (frozen down to the root
+    of their base chain) and read-only arrays of the caller -- so an in-place edit is either impossible (it raises) or the
+    array was never cached (it is uploaded again).  Recycled or dead memory misses, small arrays are never recorded, the
+    byte bound evicts the least recently used pair."""
     import gc
     import numpy as np
     from microaligner_amd.device import _ResidentCache
 
-    class Dev:
-        def __init__(self, a):
-            self.ptr, self.shape, self.dtype, self.nbytes = 1, a.shape, a.dtype, a.nbytes
-
+    monkeypatch.delenv("MICROALIGNER_RESIDENT", raising=False)
     c = _ResidentCache()
+    assert c.mode == "results"
     a = np.random.default_rng(0).random((600, 600)).astype(np.float32)
-    d = Dev(a)
-    c.remember(a, d)
-    assert c.lookup(a) is d and c.lookup(a[:]) is d and c.hits == 2      # a view of the same memory is the same array
-    assert c.lookup(a[:300]) is None and c.lookup(a.copy()) is None
-    a *= 2
-    assert c.lookup(a) is None and not c.entries                          # edited: forgotten, will be uploaded again
+    c.remember(a, _Dev(a))
+    assert not c.entries and c.lookup(a) is None              # a writable array of the caller is never recorded ...
+    a[100:200, 100:200] = 0                                   # ... so a block edit between uploads cannot be missed
+    assert c.lookup(a) is None
+
+    # what DeviceArray.numpy() does with an array it allocated: frozen to the root, then recorded
+    root = np.zeros(600 * 600 * 4, np.uint8)
+    res = root.view(np.float32).reshape(600, 600)
+    c.freeze(res)
+    assert not res.flags.writeable and not root.flags.writeable
+    d = _Dev(res)
+    c.remember(res, d)
+    assert c.lookup(res) is d and c.lookup(res[:]) is d and c.hits == 2      # a view of the same memory is the same array
+    assert c.lookup(res[:300]) is None and c.lookup(res.copy()) is None
+    with pytest.raises(ValueError, match="read-only"):
+        res[100:200, 100:200] = 0                             # the advisor's sub-stride block edit: loud, not silent
+    with pytest.raises(ValueError):
+        res.flags.writeable = True                            # numpy refuses while the root is read-only
+    root.flags.writeable = True                               # a caller who insists (root first, then the view) ...
+    res.flags.writeable = True
+    res[100:200, 100:200] = 1
+    assert c.lookup(res) is None and not c.entries            # ... is no longer a hit, and the pair is forgotten
+
+    # a read-only array of the caller is recorded; the pair dies with the host memory
     b = np.ones((600, 600), np.float32)
-    c.remember(b, Dev(b))
-    assert len(c.entries) == 1
+    b.flags.writeable = False
+    c.remember(b, _Dev(b))
+    assert len(c.entries) == 1 and c.lookup(b) is not None
     del b
     gc.collect()
-    assert not c.entries and c.bytes == 0                                 # the pair dies with the host memory
+    assert not c.entries and c.bytes == 0
     small = np.zeros(10, np.float32)
-    c.remember(small, Dev(small))
+    small.flags.writeable = False
+    c.remember(small, _Dev(small))
     assert not c.entries
     c.limit = 3 * a.nbytes
     keep = [np.full((600, 600), i, np.float32) for i in range(5)]
     for k in keep:
-        c.remember(k, Dev(k))
+        k.flags.writeable = False
+        c.remember(k, _Dev(k))
     assert len(c.entries) == 3 and c.lookup(keep[0]) is None and c.lookup(keep[4]) is not None
-    d.ptr = None
+    dead = _Dev(keep[0])
+    dead.ptr = None
+    c.remember(keep[0], dead)
+    assert c.lookup(keep[0]) is None                          # a freed device array is never handed out
+
+
+def test_resident_cache_sampled_mode_is_opt_in_and_documented_unsound(monkeypatch):
+    """MICROALIGNER_RESIDENT=sampled (the round-3 default, now opt-in): writable arrays are recorded behind a sampled
+    CRC.  Whole-array edits are noticed; a block edit that falls between the samples is NOT -- which is why it is no
+    longer the default."""
+    import numpy as np
+    from microaligner_amd.device import _ResidentCache
+
+    monkeypatch.setenv("MICROALIGNER_RESIDENT", "sampled")
+    c = _ResidentCache()
+    a = np.random.default_rng(0).random((2048, 2048)).astype(np.float32)
+    d = _Dev(a)
     c.remember(a, d)
-    assert c.lookup(a) is None                                            # a freed device array is never handed out
+    assert c.lookup(a) is d
+    step = max(1, a.nbytes // c.SAMPLES) | 1                  # the guard samples bytes 0, step, 2 step, ...
+    flat = a.reshape(-1)
+    i = next(i for i in range(500_000, 600_000) if all((4 * i + b) % step for b in range(4)))
+    flat[i] = -1.0                                            # an edit between two samples
+    assert c.lookup(a) is d                                   # the documented hole
+    a *= 2
+    assert c.lookup(a) is None and not c.entries
+    monkeypatch.setenv("MICROALIGNER_RESIDENT", "readonly")   # earlier name of today's default
+    assert _ResidentCache().mode == "results"
+    monkeypatch.setenv("MICROALIGNER_RESIDENT", "sometimes")
+    with pytest.raises(ValueError):
+        _ResidentCache()
+
+
+class _FakeDev:
+    def __init__(self, shape, dtype):
+        import numpy as np
+        self.shape, self.dtype, self.data = tuple(shape), np.dtype(dtype), np.zeros(shape, dtype)
+        self.nbytes, self.ptr = self.data.nbytes, 1
+
+
+class _FakeStreamCtx:
+    """Stand-in for device.Context with just what parallel.stream_pairs touches; copies are numpy copies, events are
+    counters, so the pipeline's threading, ordering, back-pressure and error handling run without a GPU."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.up = self.down = 0
+        self.events = 0
+        self.log = []
+
+    def sync(self): pass
+    def engine_sync(self, e): pass
+    def engine_wait(self, e, ev): pass
+    def event_sync(self, ev): pass
+    def elapsed_ms(self, a, b): return 1.0
+    def transfer_stats(self): return self.up, self.down
+
+    def event(self):
+        self.events += 1
+        return object()
+
+    def event_destroy(self, ev):
+        self.events -= 1
+
+    def engine_record(self, e, ev):
+        with self.lock:
+            self.log.append(("record", e))
+
+    def empty(self, shape, dtype):
+        return _FakeDev(shape, dtype)
+
+    def host_empty(self, shape, dtype, limit=None):
+        import numpy as np
+        return np.empty(shape, dtype)
+
+    def host_reserve(self, shape, dtype, count):
+        with self.lock:
+            self.log.append(("reserve", tuple(shape), count))
+
+    def engine_upload(self, dst, arr, engine=1):
+        dst.data[...] = arr
+        with self.lock:
+            self.up += arr.nbytes
+
+    def engine_download(self, src, out, engine=2):
+        out[...] = src.data
+        with self.lock:
+            self.down += out.nbytes
+
+
+def test_stream_pairs_pipeline_logic_without_a_gpu():
+    """parallel.stream_pairs over a stand-in context: results in input order and equal to the stage applied pair by pair,
+    lazily evaluated input, shape changes mid-stream, caller-provided outputs, byte counts, engine busy times, an
+    exception in any engine or in the input generator surfaces in the consumer, and early exit of the consumer stops the
+    engine threads."""
+    import threading
+    import numpy as np
+    from microaligner_amd import parallel
+    from microaligner_amd.device import use_context
+
+    def stage(ctx, dref, dmov):
+        flow = _FakeDev(dref.shape + (2,), np.float32)
+        flow.data[..., 0] = dref.data - dmov.data
+        flow.data[..., 1] = dref.data + dmov.data
+        warped = _FakeDev(dmov.shape, dmov.dtype)
+        warped.data[...] = dmov.data[::-1]
+        return [flow, warped], ["report"], {"sum": float(dref.data.sum())}
+
+    rng = np.random.default_rng(0)
+    shapes = [(30, 40)] * 4 + [(50, 20)] * 3 + [(30, 40)] * 2
+    pairs = [(rng.random(s).astype(np.float32), rng.random(s).astype(np.float32)) for s in shapes]
+    pulled = []
+
+    def lazy():
+        for k, p in enumerate(pairs):
+            pulled.append(k)
+            yield p
+
+    fake = _FakeStreamCtx()
+    stats = {}
+    with use_context(fake):
+        got = []
+        for res in parallel.stream_pairs(lazy(), stage=stage, depth=2, stats=stats):
+            assert len(pulled) <= res.index + 2 + 2 + 2 + 1      # bounded look-ahead: the queues between the engines
+            got.append(res)
+    assert [r.index for r in got] == list(range(len(pairs)))
+    for r, (ref, mov) in zip(got, pairs):
+        flow, warped = r
+        assert np.array_equal(flow[..., 0], ref - mov) and np.array_equal(flow[..., 1], ref + mov)
+        assert np.array_equal(warped, mov[::-1]) and r.reports == ["report"] and r.extra["sum"] == float(ref.sum())
+    assert stats["pairs"] == len(pairs) and stats["h2d_bytes"] == sum(a.nbytes + b.nbytes for a, b in pairs)
+    assert stats["d2h_bytes"] == sum(r.flow.nbytes + r.warped.nbytes for r in got)
+    assert stats["compute_busy_ms"] == len(pairs) and stats["wall_ms"] > 0
+    assert fake.events == 0                                        # every event destroyed
+    assert not [t for t in threading.enumerate() if t.name.startswith("ma-engine-")]
+
+    # caller-provided outputs (rows of a memmap in the pipeline); warp=False-like stages may return None entries
+    dst_f = np.zeros((4, 30, 40, 2), np.float32)
+    dst_w = np.zeros((4, 30, 40), np.float32)
+    with use_context(fake):
+        for res in parallel.stream_pairs(pairs[:4], stage=stage, out=lambda i: (dst_f[i], dst_w[i])):
+            assert res.flow is not None and res.flow.base is dst_f
+    assert np.array_equal(dst_f[2][..., 0], pairs[2][0] - pairs[2][1]) and np.array_equal(dst_w[3], pairs[3][1][::-1])
+
+    # errors: in the stage, in the input, in a bad output array
+    def bad_stage(ctx, dref, dmov):
+        if dref.data[0, 0] == pairs[2][0][0, 0]:
+            raise RuntimeError("boom in compute")
+        return stage(ctx, dref, dmov)
+
+    def bad_input():
+        yield pairs[0]
+        raise OSError("boom in the loader")
+
+    with use_context(fake):
+        with pytest.raises(RuntimeError, match="boom in compute"):
+            list(parallel.stream_pairs(pairs, stage=bad_stage))
+        with pytest.raises(OSError, match="boom in the loader"):
+            list(parallel.stream_pairs(bad_input(), stage=stage))
+        with pytest.raises(ValueError, match="output 0"):
+            list(parallel.stream_pairs(pairs[:2], stage=stage, out=lambda i: (np.zeros((3, 3), np.float32), None)))
+        with pytest.raises(ValueError, match="2-D"):
+            list(parallel.stream_pairs([(np.zeros((2, 2, 2), np.float32), np.zeros((2, 2), np.float32))], stage=stage))
+        # the consumer walks away after the first result: the generator's close() stops and joins the engines
+        gen = parallel.stream_pairs(pairs, stage=stage)
+        first = next(gen)
+        assert first.index == 0
+        gen.close()
+    assert not [t for t in threading.enumerate() if t.name.startswith("ma-engine-")]
+    assert fake.events == 0
 
 
 def test_nmi_of_raw_labels_is_scikit_learns():
