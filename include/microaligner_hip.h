@@ -197,7 +197,10 @@ int ma_farneback_debug(ma_ctx* ctx, const void* prev, const void* next, int dtyp
  * reference prints (factor, MI scores, accept / reject); *n_reports receives the number of levels.  The call
  * synchronises the ctx stream once per level (the gate decision needs the NMI scores on the host); on return the
  * flow is enqueued, not necessarily complete (ma_sync).  MA_EINVAL when the pyramid would be empty: where the
- * reference dies with an UnboundLocalError (:173). */
+ * reference dies with an UnboundLocalError (:173).  MA_EINVAL with "max() == 0" in ma_last_error() when a float32 image
+ * on the path (a level, or a warped level) has a maximum of exactly 0 without being all zero: the reference's dog()
+ * returns such an image unchanged (:256-257) and goes on with float labels, which this entry point does not model --
+ * microaligner_amd.OptFlowRegistrator then repeats the call with its Python level loop, which does. */
 typedef struct ma_params {
     int num_pyr_lvl;      /* 4    */
     int num_iterations;   /* 3    */
@@ -296,6 +299,11 @@ int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t 
  * cv2.normalize(.., 0, 255, NORM_MINMAX, CV_8U) (utils.py:94). */
 int ma_max_project(ma_ctx* ctx, const void* planes, int dtype, int nz, size_t n, void* dst);
 int ma_normalize_minmax_u8(ma_ctx* ctx, const void* src, int dtype, size_t n, uint8_t* dst);
+
+/* Mat::convertTo(CV_32F) of an integer image (exact).  cv2.calcOpticalFlowFarneback converts each of its two inputs to
+ * float32 on its own (optflowgf.cpp), so the reference accepts a uint8 reference image next to a uint16 moving image
+ * (flow_calc.py:33-44); the Python layer converts such a pair with this before ma_farneback_tiled. */
+int ma_convert_f32(ma_ctx* ctx, const void* src, int dtype, size_t n, float* dst);
 
 /* transform_img_with_tmat (utils.py:98-114) after padding: skimage.transform.warp(img,
  * AffineTransform(inverse_3x3), output_shape=img.shape, preserve_range=True).astype(dtype) -- bilinear,

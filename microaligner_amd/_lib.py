@@ -110,6 +110,7 @@ SIGNATURES.update({
     "ma_engine_sync": (_i, [_vp, _i]),
     "ma_event_sync": (_i, [_vp, _vp]),
     "ma_host_parallel_copy": (_i, [_vp, _vp, _sz]),
+    "ma_convert_f32": (_i, [_vp, _vp, _i, _sz, _vp]),
 })
 
 _lib = None

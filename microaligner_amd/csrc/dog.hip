@@ -77,8 +77,12 @@ struct DogScalars {
 };
 
 // normalize(src, 0, 1, NORM_MINMAX, CV_32F): scale rounded to float, shift = (float)0 - (float)(smin*scale)
-__device__ __forceinline__ void d_dog_params_in(DogScalars* s, float mn, float mx)
+// sticky (may be NULL): set to 1 when the input's maximum is exactly 0 but the image is not all zero -- the one input
+// for which the reference's dog() returns the image UNCHANGED (optflow_registrator.py:256-257) and the uint8 result
+// of this chain is not what it goes on with; ma_optflow_register reports it (register.hip)
+__device__ __forceinline__ void d_dog_params_in(DogScalars* s, float mn, float mx, int* sticky)
 {
+    if (sticky && mx == 0.f && mn < 0.f) atomicOr(sticky, 1);
     s->mm_src[0] = mn; s->mm_src[1] = mx;
     double smin = mn, smax = mx;
     double scale = (1.0 - 0.0) * (smax - smin > DBL_EPSILON ? 1. / (smax - smin) : 0);
@@ -98,14 +102,17 @@ __device__ __forceinline__ void d_dog_params_out(DogScalars* s, float mn, float 
     s->b8 = (float)shift;
 }
 // the input's (min, max) came from the kernel that produced it
-__global__ void dog_params_in(DogScalars* s, const float* __restrict__ mm) { d_dog_params_in(s, mm[0], mm[1]); }
+__global__ void dog_params_in(DogScalars* s, const float* __restrict__ mm, int* sticky)
+{
+    d_dog_params_in(s, mm[0], mm[1], sticky);
+}
 
 // one block of 1024 threads folds all partial (min, max) pairs; 4 independent 8-byte loads per lane and step
 constexpr int MMF_T = 1024;
 // sc / what: the DOG scalars that follow from this (min, max) are computed by the same thread (what = 1: the input's
 // normalisation, 2: the difference image's) instead of by a kernel of their own
 __global__ __launch_bounds__(MMF_T) void minmax_final(const float* __restrict__ part, int nparts, float* __restrict__ out,
-                                                      DogScalars* __restrict__ sc, int what)
+                                                      DogScalars* __restrict__ sc, int what, int* sticky = nullptr)
 {
     float lo = INFINITY, hi = -INFINITY;
     const float2* p2 = reinterpret_cast<const float2*>(part);
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(MMF_T) void minmax_final(const float* __restrict__ 
     if (threadIdx.x == 0) {
         for (int k = 1; k < MMF_T / 64; k++) { lo = fminf(lo, slo[k]); hi = fmaxf(hi, shi[k]); }
         if (out) { out[0] = lo; out[1] = hi; }
-        if (what == 1) d_dog_params_in(sc, lo, hi);
+        if (what == 1) d_dog_params_in(sc, lo, hi, sticky);
         else if (what == 2) d_dog_params_out(sc, lo, hi);
     }
 }
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(MMF_T) void minmax_final(const float* __restrict__ 
 constexpr int MM_BLOCKS = 2048;
 
 int launch_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, float* part, float* out2, DogScalars* sc = nullptr,
-                  int what = 0)
+                  int what = 0, int* sticky = nullptr)
 {
     int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
     if (blocks > MM_BLOCKS) blocks = MM_BLOCKS;
@@ -142,7 +149,7 @@ int launch_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, float* part
     if (dtype == MA_U8) hipLaunchKernelGGL((minmax_partial<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint8_t*)src, n, part);
     else if (dtype == MA_U16) hipLaunchKernelGGL((minmax_partial<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, (const uint16_t*)src, n, part);
     else hipLaunchKernelGGL((minmax_partial<float>), dim3(blocks), dim3(256), 0, ctx->stream, (const float*)src, n, part);
-    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, blocks, out2, sc, what);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, blocks, out2, sc, what, sticky);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }
@@ -488,6 +495,13 @@ __global__ __launch_bounds__(256) void max_project_kernel(const T* __restrict__ 
     }
 }
 
+// Mat::convertTo(CV_32F) of an integer image: exact
+template <typename T>
+__global__ __launch_bounds__(256) void convert_f32_kernel(const T* __restrict__ src, size_t n, float* __restrict__ dst)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+
 // getGaussianKernel(ksize, sigma, CV_32F) as OpenCV 4.x computes it (A.5): taps in double,
 // sum = 2*sum(t)+1, multiplied by 1/sum, rounded to float once.
 void gaussian_kernel(int ksize, double sigma, std::vector<float>& k)
@@ -557,7 +571,8 @@ size_t ma_dog_workspace_bytes(int h, int w, int low_sigma) { return dog_plan(h, 
 
 int ma_launch_minmax_final(ma_ctx* ctx, const float* part, int nparts, float* out2)
 {
-    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, nparts, out2, (DogScalars*)nullptr, 0);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, nparts, out2, (DogScalars*)nullptr, 0,
+                       (int*)nullptr);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }
@@ -623,9 +638,9 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
     MaProfScope ps(ctx, MA_K_DOG, (double)n);
     // the scalars of the two normalisations are computed by the last thread of the reduction they follow from
     if (src_minmax_dev) {  // the producer of `src` already reduced it
-        hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc, src_minmax_dev);
+        hipLaunchKernelGGL(dog_params_in, dim3(1), dim3(1), 0, ctx->stream, sc, src_minmax_dev, ctx->dog_sticky);
     } else {
-        MA_TRY(launch_minmax(ctx, src, dtype, n, part, nullptr, sc, 1));
+        MA_TRY(launch_minmax(ctx, src, dtype, n, part, nullptr, sc, 1, ctx->dog_sticky));
     }
     if (fused) {
         const dim3 grid(ma_xcd_grid((long long)nblk)), block(64 * DF_NW);
@@ -661,7 +676,8 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
         else { if (fblur) MA_DOG_COLS(16, true); else MA_DOG_COLS(16, false); }
 #undef MA_DOG_COLS
     }
-    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, (int)nblk, (float*)nullptr, sc, 2);
+    hipLaunchKernelGGL(minmax_final, dim3(1), dim3(MMF_T), 0, ctx->stream, part, (int)nblk, (float*)nullptr, sc, 2,
+                       (int*)nullptr);
     hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst, fscale);
     MA_HIP(hipGetLastError());
     if (src_max_is_zero_host) {
@@ -690,6 +706,21 @@ int ma_dog_u8_minmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, int 
 {
     MA_REQUIRE(src_minmax_dev, "NULL argument");
     return dog_u8_impl(ctx, src, dtype, h, w, low_sigma, high_sigma, dst, src_max_is_zero_host, src_minmax_dev, 0);
+}
+
+int ma_convert_f32(ma_ctx* ctx, const void* src, int dtype, size_t n, float* dst)
+{
+    MA_REQUIRE(ctx && src && dst, "NULL argument");
+    MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
+    MA_REQUIRE(n > 0, "empty array");
+    MA_HIP(hipSetDevice(ctx->device));
+    if (dtype == MA_F32) return ma_memcpy_d2d(ctx, dst, src, n * sizeof(float));
+    MaProfScope ps(ctx, MA_K_OTHER, (double)n);
+    dim3 grid(grid_for(n)), block(256);
+    if (dtype == MA_U8) hipLaunchKernelGGL((convert_f32_kernel<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)src, n, dst);
+    else hipLaunchKernelGGL((convert_f32_kernel<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)src, n, dst);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
 }
 
 int ma_max_project(ma_ctx* ctx, const void* planes, int dtype, int nz, size_t n, void* dst)

@@ -75,6 +75,10 @@ struct ma_ctx {
     MaStageRing* stage[2] = {nullptr, nullptr};   // [0] host -> device, [1] device -> host; each used by one thread at a time
     // MA_OPT_COMPANION_STREAM
     bool companion = true;
+    // device int that the dog() chain sets when an input has max() == 0 but is not all zero (see d_dog_params_in);
+    // NULL outside ma_optflow_register
+    int* dog_sticky = nullptr;
+    int* dog_sticky_buf = nullptr;   // the allocation behind it (owned by the ctx)
     // companion ctx (own stream and workspace, same device) for the work of ma_optflow_register that does not depend on
     // the flow -- dog(ref) and dog(mov) of every level -- and the events that order the two streams; created on first use
     ma_ctx* side = nullptr;

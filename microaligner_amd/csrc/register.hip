@@ -126,6 +126,16 @@ int dog_level(ma_ctx* ctx, const void* img, int dtype, int h, int w, const float
     return ma_dog_u8_ex(run_on ? run_on : ctx, img, dtype, h, w, 5, 9, flags, minmax_dev, (uint8_t*)out.p, nullptr);
 }
 
+// points the dog() chain of ctx and of its companion at the ctx's sticky "max() == 0, not all zero" flag for the
+// duration of a call
+struct StickyScope {
+    ma_ctx *ctx, *side;
+    bool on;
+    StickyScope(ma_ctx* c, ma_ctx* s, bool enable) : ctx(c), side(s), on(enable) {}
+    void arm() { ctx->dog_sticky = ctx->dog_sticky_buf; side->dog_sticky = ctx->dog_sticky_buf; }
+    ~StickyScope() { ctx->dog_sticky = nullptr; side->dog_sticky = nullptr; }
+};
+
 // waits for the companion stream before the buffers it writes can go back to the cache (error paths; a no-op otherwise)
 struct SideDrain {
     ma_ctx* side;
@@ -234,9 +244,11 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
         if (c > max_chunks) max_chunks = c;
     }
     MA_REQUIRE(max_chunks <= 65535, "too many NMI chunks");
-    MA_TRY(ma_pinned_reserve(ctx, 2 * max_chunks * sizeof(double)));
+    MA_TRY(ma_pinned_reserve(ctx, 2 * max_chunks * sizeof(double) + 64));
     double* sc_after = (double*)ctx->pinned;
     double* sc_before = sc_after + max_chunks;
+    int* sticky_host = (int*)(sc_before + max_chunks);
+    *sticky_host = 0;
 
     // dog(ref) and dog(mov) of every level depend on the pyramids only: the companion stream computes them, coarsest level
     // first, while this stream walks the levels -- the two full-resolution images are filtered under the coarse levels'
@@ -255,6 +267,14 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
             if (b > need) need = b;
         }
         MA_TRY(ma_ws_reserve(side, need));
+    }
+    // float images only: every dog() of this call reports an input whose max() is 0 without being all zero (integer
+    // images cannot be negative, there max() == 0 IS all zero and the uint8 zero image is what the reference goes on with)
+    StickyScope sticky(ctx, side, dtype == MA_F32);
+    if (dtype == MA_F32) {
+        if (!ctx->dog_sticky_buf) MA_HIP(hipMalloc((void**)&ctx->dog_sticky_buf, 64));
+        MA_HIP(hipMemsetAsync(ctx->dog_sticky_buf, 0, sizeof(int), ctx->stream));
+        sticky.arm();
     }
     std::vector<Buf> ref_dogs(n_lvl), raw_dogs(n_lvl);
     SideDrain drain{side != ctx ? side : nullptr};   // declared after the buffers: destroyed (drained) before they are released
@@ -336,7 +356,15 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
                                       npx, chunk, sc_after, sc_before, (int)max_chunks, &n_after));
             n_before = n_after;
         }
+        if (dtype == MA_F32)
+            MA_HIP(hipMemcpyAsync(sticky_host, ctx->dog_sticky_buf, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MA_HIP(hipStreamSynchronize(ctx->stream));   // the one host round trip of the level
+        if (*sticky_host) {
+            ma_set_error("invalid argument: a float image on the path (level %d of %d, %d x %d) has max() == 0 without being "
+                         "all zero; the reference's dog() returns it unchanged (optflow_registrator.py:256-257), which only "
+                         "the Python level loop models (engine='python')", lvl, n_lvl, h, w);
+            return MA_EINVAL;
+        }
         // the stream is idle: settle the per-kernel accounting now, so that its events are reused level after level
         // (a profiled run that only ever creates events stalls for ~0.2 s once the runtime's signal pool has to grow)
         if (ctx->profile) MA_TRY(ma_profile_flush(ctx));

@@ -517,8 +517,12 @@ class Context:
     def farneback(self, prev, nxt, winsize, iterations, tile=0, overlap=0, poly_n=1, poly_sigma=1.7, fused=False):
         """cv2.calcOpticalFlowFarneback(prev, next, levels=0, GAUSSIAN) on the whole image (tile=0)
         or on TileFlowCalc's overlapping windows, stitched (flow_calc.py:59-98)."""
-        if prev.shape != nxt.shape or prev.dtype != nxt.dtype or prev.ndim != 2:
-            raise ValueError("prev/next must be 2-D arrays of the same shape and dtype")
+        if prev.shape != nxt.shape or prev.ndim != 2:
+            raise ValueError("prev/next must be 2-D arrays of the same shape")
+        if prev.dtype != nxt.dtype:
+            # cv2.calcOpticalFlowFarneback converts each input to float32 on its own (exact for integers): a mixed pair
+            # is the float32 pair
+            prev, nxt = self.to_f32(prev), self.to_f32(nxt)
         H, W = prev.shape
         flow = self.empty((H, W, 2), np.float32)
         self._run(self.lib.ma_farneback_tiled, prev.ptr, nxt.ptr, _dt(prev.dtype), H, W, int(tile),
@@ -798,6 +802,14 @@ class Context:
                   cs.ctypes.data_as(C.POINTER(C.c_double)), of.ctypes.data_as(C.POINTER(C.c_double)), d_tile.ptr, d_xy.ptr,
                   n, desc.ptr)
         return desc if on_device else desc.numpy()
+
+    def to_f32(self, arr):
+        """Mat::convertTo(CV_32F): exact for the integer dtypes (ma_convert_f32); float32 arrays pass through."""
+        if arr.dtype == np.float32:
+            return arr
+        out = self.empty(arr.shape, np.float32)
+        self._run(self.lib.ma_convert_f32, arr.ptr, _dt(arr.dtype), arr.size, out.ptr)
+        return out
 
     def normalize_minmax_u8(self, arr):
         out = self.empty(arr.shape, np.uint8)

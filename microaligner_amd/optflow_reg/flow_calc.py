@@ -45,8 +45,6 @@ class TileFlowCalc:
         ref, mov = ctx.asdevice(self.ref_img), ctx.asdevice(self.mov_img)
         if ref.shape != mov.shape or ref.ndim != 2:
             raise ValueError(f"ref/mov must be 2-D images of equal shape, got {ref.shape} and {mov.shape}")
-        if mov.dtype != ref.dtype:
-            raise ValueError(f"ref/mov dtypes differ: {ref.dtype} vs {mov.dtype}")
         tiled = is_tiled(ref.shape, self.tile_size)
         flow = ctx.farneback(mov, ref, self.win_size, self.num_iter,
                              tile=self.tile_size if tiled else 0, overlap=self.overlap if tiled else 0,

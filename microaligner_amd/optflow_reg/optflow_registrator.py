@@ -59,8 +59,12 @@ class OptFlowRegistrator:
         # (MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE); default: the SSE2 baseline arithmetic
         self.dog_muladd_fused = False
         # "c": the level loop runs inside the library (ma_optflow_register, one C call); "python": the same loop stated
-        # here over the primitive entry points (the second implementation the tests compare the first with)
+        # here over the primitive entry points (the second implementation the tests compare the first with, and the one
+        # that serves the two input classes the C entry point does not model: reference and moving image of different
+        # dtypes, and float images whose max() is 0 without being all zero)
         self.engine = "c"
+        # True: the mov_img GETTER returns the reference image, as the reference's does (optflow_registrator.py:73-74)
+        self.compat_mov_getter = False
         self.level_reports: List[LevelReport] = []
         self._warper = Warper()
         self._tile_flow_calc = TileFlowCalc()
@@ -77,9 +81,9 @@ class OptFlowRegistrator:
 
     @property
     def mov_img(self):
-        # the reference's getter returns the *reference* image (optflow_registrator.py:73-74, quirk
-        # Q4); this one returns what was set
-        return self._mov_img
+        # the reference's getter returns the *reference* image (optflow_registrator.py:73-74, quirk Q4); this one
+        # returns what was set unless compat_mov_getter asks for the reference's behaviour
+        return self._ref_img if self.compat_mov_getter else self._mov_img
 
     @mov_img.setter
     def mov_img(self, img):
@@ -124,12 +128,22 @@ class OptFlowRegistrator:
 
         ref_full, mov_full = ctx.asdevice(self._ref_img), ctx.asdevice(self._mov_img)
         self._full_shape = ref_full.shape
-        if self.engine == "c":
-            if ref_full.dtype != mov_full.dtype:
-                raise ValueError(f"ref/mov dtypes differ: {ref_full.dtype} vs {mov_full.dtype}")
-            result, reports = ctx.optflow_register(
-                ref_full, mov_full, self.num_pyr_lvl, self.num_iterations, self.tile_size, self.overlap,
-                self.use_full_res_img, self.use_dog, L.MA_FB_MULADD_FUSED if self.muladd_fused else 0, self._dog_flags())
+        if self.engine not in ("c", "python"):
+            raise ValueError(f"unknown engine {self.engine!r}: 'c' or 'python'")
+        reports = None
+        # images of different dtypes (each keeps its own pyramid arithmetic, cv2 converts per input): the Python loop
+        if self.engine == "c" and ref_full.dtype == mov_full.dtype:
+            try:
+                result, reports = ctx.optflow_register(
+                    ref_full, mov_full, self.num_pyr_lvl, self.num_iterations, self.tile_size, self.overlap,
+                    self.use_full_res_img, self.use_dog, L.MA_FB_MULADD_FUSED if self.muladd_fused else 0,
+                    self._dog_flags())
+            except ValueError as e:
+                if "max() == 0" not in str(e):
+                    raise
+                # a float image with max() == 0 that is not all zero: dog() returns it unchanged in the reference
+                # (:256-257); the loop below follows it there
+        if reports is not None:
             for factor, shape, after, before, accepted in reports:
                 self._log("Pyramid factor", factor)
                 self._log("    MI score after:", after, "| MI score before:", before)
@@ -137,8 +151,6 @@ class OptFlowRegistrator:
                 self.level_reports.append(LevelReport(factor, tuple(shape), float(after), float(before), accepted))
             self._ctx = None
             return result if device_in else result.numpy()
-        if self.engine != "python":
-            raise ValueError(f"unknown engine {self.engine!r}: 'c' or 'python'")
         ref_pyr, factors = self._generate_img_pyr(ref_full)
         mov_pyr, _ = self._generate_img_pyr(mov_full)
 
@@ -247,10 +259,18 @@ class OptFlowRegistrator:
         return {1: (5, 9), 2: (4, 7), 4: (3, 5), 8: (2, 3), 16: (1, 2)}[pyr_factor]
 
     def _dog_dev(self, img: DeviceArray, low_sigma: int = 5, high_sigma: int = 9):
-        """dog(img, True) for register(): stays on the stream.  Where the reference returns an image whose max
-        is 0 unchanged (:256-257) this yields the all-zero uint8 image, which every consumer on the path
-        (Farneback's convertTo float, the NMI labels) treats identically for the all-zero image that case means."""
-        return get_context().dog_u8(img, low_sigma, high_sigma, flags=self._dog_flags())
+        """dog(img, True) for the Python level loop.  Where the reference returns an image whose max is 0 unchanged
+        (:256-257): an all-zero image becomes the all-zero uint8 image, which every consumer on the path (Farneback's
+        convertTo float, the NMI labels) treats identically; a float image with max() == 0 that is NOT all zero is
+        returned unchanged like the reference's (Farneback converts a mixed pair per input, the gate labels the raw
+        values: shared_modules/similarity_scoring.py).  Integer images cannot be negative: no check, no host sync."""
+        ctx = get_context()
+        if img.dtype != np.float32:
+            return ctx.dog_u8(img, low_sigma, high_sigma, flags=self._dog_flags())
+        out, src_max_is_zero = ctx.dog_u8(img, low_sigma, high_sigma, report_zero=True, flags=self._dog_flags())
+        if src_max_is_zero and ctx.minmax(img)[0] < 0:
+            return img
+        return out
 
     def _dog_flags(self) -> int:
         f = self.dog_muladd_fused

@@ -497,11 +497,14 @@ def register_cycle_chain(cycles: Sequence, ref_channel_ids=None, params: Optiona
 
 
 def align_pairs(pairs: Sequence, feature_params: Optional[dict] = None, optflow_params: Optional[dict] = None,
-                gather: bool = True, lanes: int = 1):
+                gather: bool = True, lanes: int = 1, stream: Optional[bool] = None):
     """Two-stage alignment of independent (ref, mov) pairs -- mosaic tiles, BASELINE cfg5 -- sharded over the ranks:
     feature-based affine initialisation (FeatureRegistrator, the pipeline's first stage, __main__.py:257-286),
     transform_img_with_tmat, then the optical-flow refinement and warp (OptFlowRegistrator + Warper, :398-433).
-    Returns, per pair and in pair order on rank 0, (aligned moving image, 2x3 matrix, flow)."""
+    Returns, per pair and in pair order on rank 0, (aligned moving image, 2x3 matrix, flow).
+    stream (default: on for host pairs of equal shape when lanes == 1): the rank's share goes through stream_pairs, the
+    two stages of pair k running on the device arrays while pair k+1 is uploaded and pair k-1 downloaded."""
+    import numpy as np
     from . import FeatureRegistrator, OptFlowRegistrator, Warper, transform_img_with_tmat
     feature_params, optflow_params = dict(feature_params or {}), dict(optflow_params or {})
 
@@ -525,4 +528,39 @@ def align_pairs(pairs: Sequence, feature_params: Optional[dict] = None, optflow_
         w.image, w.flow = affine, flow
         return w.warp(), t_mat, flow
 
-    return run_sharded(pairs, one, gather=gather, lanes=lanes)
+    def stage(ctx, dref, dmov):
+        # the same statements on device arrays (transform_img_with_tmat: utils.py:98-114 without the padding, the shapes
+        # are equal here)
+        freg = FeatureRegistrator()
+        freg.verbose = False
+        for k, v in feature_params.items():
+            setattr(freg, k, v)
+        freg.ref_img, freg.mov_img = dref, dmov
+        t_mat = freg.register()
+        identity = np.array([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+        if np.array_equal(t_mat, identity):
+            affine = dmov
+        else:
+            affine = ctx.warp_affine(dmov, np.linalg.pinv(np.append(np.asarray(t_mat, dtype=np.float64), [[0, 0, 1]], axis=0)))
+        oreg = OptFlowRegistrator()
+        oreg.verbose = False
+        for k, v in optflow_params.items():
+            setattr(oreg, k, v)
+        oreg.ref_img, oreg.mov_img = dref, affine
+        flow = oreg.register()
+        return [ctx.warp(affine, flow, oreg.tile_size, oreg.overlap), flow], oreg.level_reports, t_mat
+
+    rank, ws = world()
+    mine = shard(len(pairs), rank, ws)
+    same = all(isinstance(pairs[i][0], np.ndarray) and isinstance(pairs[i][1], np.ndarray)
+               and pairs[i][0].shape == pairs[i][1].shape and pairs[i][0].dtype == pairs[i][1].dtype for i in mine)
+    if stream is None:
+        stream = lanes <= 1 and same and len(mine) > 1
+    if not stream:
+        return run_sharded(pairs, one, gather=gather, lanes=lanes)
+    if not same:
+        raise ValueError("stream=True needs host (numpy) pairs whose two images have the same shape and dtype")
+    local = {}
+    for res in stream_pairs((pairs[i] for i in mine), stage=stage):
+        local[mine[res.index]] = (res.flow, res.extra, res.warped)   # stage order: [warped image, flow]
+    return _gather(local, len(pairs), gather)

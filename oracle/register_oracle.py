@@ -59,6 +59,10 @@ def stitch_tiles(tiles, grid, shape, tile, overlap):
 
 # ---- flow_calc.py:59-98 -------------------------------------------------------------------------------
 def tile_flow(ref, mov, tile, overlap, win_size, num_iter, fused=False, nthreads=1):
+    if ref.dtype != mov.dtype:
+        # cv2.calcOpticalFlowFarneback converts prev and next to CV_32F separately (optflowgf.cpp): a mixed pair is the
+        # float32 pair (exact for uint8 / uint16)
+        ref, mov = ref.astype(np.float32), mov.astype(np.float32)
     if max(ref.shape) / tile < 2:
         return O.calc_optical_flow_farneback(mov, ref, win_size, num_iter, fused=fused)
     rt, grid = split_tiles(ref, tile, overlap)
@@ -98,6 +102,15 @@ def merge_flows(f1, f2, tile, overlap):
 
 # ---- similarity_scoring.py:27-68 ----------------------------------------------------------------------
 def mi_tiled(a, b, tile):
+    if a.dtype != np.uint8 or b.dtype != np.uint8:
+        # dog() returned an image unchanged (max() == 0, optflow_registrator.py:256-257): the reference hands the raw
+        # values to scikit-learn as labels (similarity_scoring.py:36,44); so does the oracle
+        from sklearn.metrics import normalized_mutual_info_score
+        fa, fb = np.ravel(a), np.ravel(b)
+        if max(a.shape) / tile < 2:
+            return normalized_mutual_info_score(fa, fb)
+        chunk = tile * tile
+        return np.mean([normalized_mutual_info_score(fa[i:i + chunk], fb[i:i + chunk]) for i in range(0, fa.size, chunk)])
     if max(a.shape) / tile < 2:
         return O.nmi_u8(a, b)
     return np.mean(O.nmi_u8_chunks(a, b, tile * tile))

@@ -481,6 +481,12 @@ def test_affine_init_then_optical_flow_refine():
                                                 dict(num_pyr_lvl=2, tile_size=400, overlap=60, use_full_res_img=True,
                                                      use_dog=True))
     assert np.array_equal(final2, final) and np.array_equal(T2, T) and np.array_equal(flow2, flow)
+    # ... and, for more than one pair, runs them through the three-engine stream (device arrays end to end): same bits
+    of_params = dict(num_pyr_lvl=2, tile_size=400, overlap=60, use_full_res_img=True, use_dog=True)
+    streamed = parallel.align_pairs([(ref, mov), (ref, mov[::-1].copy()), (ref, mov)], dict(num_pyr_lvl=2, tile_size=500), of_params)
+    assert len(streamed) == 3
+    for final3, T3, flow3 in (streamed[0], streamed[2]):
+        assert np.array_equal(final3, final) and np.array_equal(T3, T) and np.array_equal(flow3, flow)
     inner = (slice(120, -120), slice(120, -120))
     err = [np.abs(a[inner].astype(np.float64) - ref[inner]).mean() for a in (mov, affine, final)]
     assert err[1] < 0.5 * err[0] and err[2] < 0.8 * err[1]

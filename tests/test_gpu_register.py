@@ -118,6 +118,72 @@ def test_c_level_loop_equals_the_python_level_loop(unrelated, dtype, params):
     assert np.array_equal(out["c"][0], exp) and [r[4] for r in out["c"][1]] == [r[3] for r in reports]
 
 
+def test_float_image_with_zero_max_follows_the_reference(ctx):
+    """A float image whose max() is exactly 0 without being all zero (here: negated images; and every warp of such an
+    image, whose constant border is 0) comes out of the reference's dog() UNCHANGED (optflow_registrator.py:256-257): the
+    reference goes on with the raw float image as Farneback input and as scikit-learn labels.  The C entry point reports
+    the case (ma_last_error: "max() == 0"), OptFlowRegistrator repeats the call with its Python level loop, which
+    follows the reference there: decisions, MI scores and flow equal the oracle orchestration (which labels through
+    scikit-learn itself)."""
+    from microaligner_amd import _lib as L
+    ref0, mov0 = synthetic.make_pair(520, 610, seed=5)
+    ref, mov = -(ref0 - ref0.min()), -(mov0 - mov0.min())
+    assert ref.max() == 0 and mov.max() == 0 and ref.min() < 0 and mov.min() < 0
+    params = dict(num_pyr_lvl=1, use_full_res_img=True, use_dog=True, tile_size=200, overlap=30)
+    exp, reports = RO.register(ref, mov, **params)
+    with pytest.raises(ValueError, match=r"max\(\) == 0"):
+        ctx.optflow_register(ctx.asdevice(ref), ctx.asdevice(mov), **params)
+    for engine in ("c", "python"):
+        reg = make_reg(dict(params, engine=engine))
+        reg.ref_img, reg.mov_img = ref, mov
+        got = reg.register()
+        assert [r.accepted for r in reg.level_reports] == [r[3] for r in reports]
+        np.testing.assert_allclose([(r.mi_after, r.mi_before) for r in reg.level_reports], [r[1:3] for r in reports],
+                                   rtol=0, atol=1e-12)
+        assert np.array_equal(got, exp)
+    # the flag is per call: an ordinary pair right after it goes through the C entry point again
+    flow, rep = ctx.optflow_register(ctx.asdevice(ref0), ctx.asdevice(mov0), **params)
+    assert np.array_equal(flow.numpy(), RO.register(ref0, mov0, **params)[0])
+    # an all-zero float image is not that case (it IS the all-zero label image): no error
+    zero = np.zeros_like(ref0)
+    flow, rep = ctx.optflow_register(ctx.asdevice(ref0), ctx.asdevice(zero), **params)
+    assert np.array_equal(flow.numpy(), RO.register(ref0, zero, **params)[0])
+
+
+@pytest.mark.parametrize("dt_ref,dt_mov,use_dog", [(np.uint8, np.uint16, False), (np.float32, np.uint8, False),
+                                                   (np.uint16, np.float32, True)])
+def test_reference_and_moving_image_of_different_dtypes(ctx, dt_ref, dt_mov, use_dog):
+    """cv2.calcOpticalFlowFarneback converts each input to float32 on its own, so the reference accepts e.g. a uint8
+    reference image with a uint16 moving image (flow_calc.py:33-44); every other step handles one image at a time in
+    its own dtype.  register(), TileFlowCalc and farneback() take such pairs: results equal the oracle's."""
+    from microaligner_amd import TileFlowCalc, farneback
+    from oracle import oracle as O
+    ref, _ = synthetic.make_pair(520, 610, seed=6, dtype=dt_ref)
+    _, mov = synthetic.make_pair(520, 610, seed=6, dtype=dt_mov)
+    params = dict(num_pyr_lvl=1, use_full_res_img=True, use_dog=use_dog, tile_size=200, overlap=30)
+    exp, reports = RO.register(ref, mov, **params)
+    reg = make_reg(params)
+    reg.ref_img, reg.mov_img = ref, mov
+    got = reg.register()
+    assert [r.accepted for r in reg.level_reports] == [r[3] for r in reports]
+    assert np.array_equal(got, exp)
+    w = Warper()
+    w.tile_size, w.overlap = 200, 30
+    w.image, w.flow = mov, got
+    assert np.array_equal(w.warp(), RO.warp(mov, exp, 200, 30))
+    fc = TileFlowCalc()
+    fc.tile_size, fc.overlap, fc.win_size, fc.num_iter = 200, 30, 29, 2
+    fc.ref_img, fc.mov_img = ref, mov
+    assert np.array_equal(fc.calc_flow(), RO.tile_flow(ref, mov, 200, 30, 29, 2))
+    assert np.array_equal(farneback(mov, ref, 0, 21, 2),
+                          O.calc_optical_flow_farneback(mov.astype(np.float32), ref.astype(np.float32), 21, 2))
+    reg.compat_mov_getter = True             # Q4: the reference's mov_img getter returns the REFERENCE image
+    reg.ref_img, reg.mov_img = ref, mov
+    assert reg.mov_img is ref
+    reg.compat_mov_getter = False
+    assert reg.mov_img is mov
+
+
 def test_two_streams_reuse_cached_buffers_without_races(ctx):
     """ma_optflow_register runs the flow-independent dog() calls on a companion stream into buffers of the context's
     cache.  Pairs of different sizes and parameters registered back to back, device resident, never synchronised in
