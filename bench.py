@@ -422,6 +422,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="pairs in flight for the informational multi-lane leg (0: skip)")
     ap.add_argument("--stream-pairs", type=int, default=12,
                     help="distinct pairs of the informational numpy -> numpy stream leg (parallel.stream_pairs; 0: skip)")
+    ap.add_argument("--no-shared-results", action="store_true",
+                    help="N > 1: skip writing every rank's last flow / warped image into the node-wide shared array")
     ap.add_argument("--no-companion", action="store_true",
                     help="MA_OPT_COMPANION_STREAM = 0: every kernel alone on the chip (per-kernel timings comparable from "
                          "run to run; the step is ~3 ms longer)")
@@ -479,14 +481,35 @@ def main():
             dist.barrier()
         mine = 1e-3 * args.steps * (1 + 0.01 * rank)
         elapsed = reduce_max(mine)
+        # the data plane of a sharded run without GPUs: units are LOADERS (evaluated in the owning rank only), results are
+        # written by each rank into a node-wide shared array (parallel.shared_array: POSIX shared memory), nothing but a
+        # barrier crosses the control plane; rank 0 then finds every row written by the rank that owns it
+        import numpy as np
+        from microaligner_amd import parallel
+        n_units = pairs_per_step
+        loaded = []
+        name = f"ma_bench_dry_{os.environ.get('MASTER_PORT', os.getpid())}"
+        store = parallel.shared_array(name, (n_units, 4, 8), np.float32)
+
+        def loader(i):
+            def load():
+                loaded.append(i)
+                return i
+            return load
+
+        parallel.run_sharded([loader(i) for i in range(n_units)], lambda u: np.full((4, 8), 1000 * rank + u, np.float32),
+                             out=store)
+        shared_ok = bool(all(np.all(store[i] == 1000 * (i % world) + i) for i in range(n_units)))
         rows = rank_table(dist, world, rank, {"rank": rank, "ms_per_step": mine / args.steps * 1e3, "pairs": my_pairs,
-                                               "device": None, "pci_bus_id": None})
+                                               "device": None, "pci_bus_id": None, "units_loaded": sorted(loaded)})
+        parallel.shared_array_unlink(name)
         if rank == 0:
             per = [r["ms_per_step"] for r in rows]
             print(json.dumps({"metric": METRIC, "value": None, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "dry_run": True,
                               "config": {"workload": args.workload, "pairs_per_step": pairs_per_step},
-                              "ranks": rows,
+                              "ranks": rows, "results_via": "shared memory array written in place by the owning rank",
+                              "shared_results_ok": shared_ok,
                               "rank_ms_per_step": {"min": min(per), "mean": sum(per) / len(per), "max": max(per)}}))
         if dist is not None:
             dist.barrier()
@@ -604,6 +627,36 @@ def main():
         flow, warped = out
         summary = {"pair": my_pairs[-1] if my_pairs else None, "flow_minmax": [float(v) for v in ctx.minmax(flow)],
                    "warped_minmax": [float(v) for v in ctx.minmax(warped)]}
+    # the data plane of a multi-rank job: each rank's download engine writes its (last) flow and warped image straight into
+    # a node-wide shared array (parallel.shared_array; the reference writes pages into its memmapped output,
+    # __main__.py:116-132) -- nothing but reports crosses the control plane
+    shared_ms, shared_note = None, None
+    if world > 1 and out is not None and not args.no_shared_results:
+        from microaligner_amd import parallel
+        name = f"ma_bench_{os.environ.get('MASTER_PORT', '0')}"
+        need = world * (H * W * 8 + H * W * np.dtype(np_dtype).itemsize)
+        try:
+            st = os.statvfs("/dev/shm")
+            room = st.f_bavail * st.f_frsize
+        except OSError:
+            room = 0
+        # one decision for all ranks (a collective inside must never be entered by some ranks only)
+        go = -reduce_max(-(1.0 if (rank != 0 or room > 1.2 * need) else 0.0)) > 0.5
+        if go:
+            ts0 = time.perf_counter()
+            flows = parallel.shared_array(name + "_flow", (world, H, W, 2), np.float32)
+            warps = parallel.shared_array(name + "_warp", (world, H, W), np_dtype)
+            out[0].numpy(out=flows[rank])
+            out[1].numpy(out=warps[rank])
+            dist.barrier()
+            shared_ms = (time.perf_counter() - ts0) * 1e3
+            if rank == 0:   # every rank's rows arrived: a strided sample per rank, next to what the rank reports over gloo
+                shared_note = [float(flows[r][::997, ::991].sum()) for r in range(world)]
+            del flows, warps
+            parallel.shared_array_unlink(name + "_flow")
+            parallel.shared_array_unlink(name + "_warp")
+        else:
+            shared_note = f"skipped: /dev/shm has {room / 2 ** 30:.0f} GiB free, {need / 2 ** 30:.0f} GiB needed"
     info = device_info(dev_index)
     rows = rank_table(dist, world, rank, {
         "rank": rank, "device": dev_index, "pci_bus_id": info["pci_bus_id"], "name": info["name"],
@@ -664,6 +717,8 @@ def main():
             "ranks": rows,
             "rank_ms_per_step": {"min": min(per), "mean": round(sum(per) / len(per), 3), "max": max(per)},
             "gather_ms": round(gather_ms, 3),
+            "results_to_shared_array_ms": round(shared_ms, 1) if shared_ms is not None else None,
+            "results_to_shared_array": shared_note,
         }
         if keep_host and not args.fused:
             res["variants"] = {}

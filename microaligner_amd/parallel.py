@@ -58,12 +58,20 @@ def release_lane_contexts():
         _lane_contexts.pop(key).close()
 
 
+def _unit(units: Sequence, i: int):
+    """Unit i, materialised HERE: a unit may be a loader -- a zero-argument callable that reads or builds the inputs
+    (pages of a TIFF, a crop of a memmap) -- so that only the rank that owns it ever touches its data (SURVEY 8e:
+    "inputs read/generated in the worker")."""
+    u = units[i]
+    return u() if callable(u) else u
+
+
 def _run_local(units: Sequence, mine: List[int], fn: Callable, lanes: int):
     """fn over this rank's units; with lanes > 1, `lanes` threads each drive their own context on the rank's
     device and pull units from a shared queue, so that several units are in flight on the GPU at once (the
     kernels of one unit fill the launch tails and host round trips of another: +3..5 % on 16384^2 pairs)."""
     if lanes <= 1 or len(mine) <= 1:
-        return {i: fn(units[i]) for i in mine}
+        return {i: fn(_unit(units, i)) for i in mine}
     import threading
     from .device import use_context
     todo, lock, results, errors = list(reversed(mine)), threading.Lock(), {}, []
@@ -79,7 +87,7 @@ def _run_local(units: Sequence, mine: List[int], fn: Callable, lanes: int):
                         if not todo:
                             break
                         i = todo.pop()
-                    results[i] = fn(units[i])
+                    results[i] = fn(_unit(units, i))
                 ctxs[k].sync()
         except BaseException as e:  # surfaced on the calling thread
             errors.append(e)
@@ -94,18 +102,85 @@ def _run_local(units: Sequence, mine: List[int], fn: Callable, lanes: int):
     return results
 
 
-def run_sharded(units: Sequence, fn: Callable, gather: bool = True, dst: int = 0, lanes: int = 1):
-    """Apply `fn(unit)` to this rank's share of `units`.
+def shared_array(name: str, shape, dtype, directory: str = "/dev/shm"):
+    """A node-wide array every rank maps: rank 0 creates `directory/name` (POSIX shared memory by default; any path
+    works, e.g. next to the output TIFF), the others open it after a barrier.  COLLECTIVE (every rank calls it with
+    the same arguments).  This is where results of a sharded run go instead of being pickled through the control plane:
+    each rank's download engine writes its rows in place (run_sharded / register_pairs `out=`), the way the reference
+    writes every page straight into its memmapped output (__main__.py:116-132).  Remove it with shared_array_unlink."""
+    import numpy as np
+    rank, ws = world()
+    path = os.path.join(directory, name)
+    shape = tuple(int(v) for v in shape)
+    if rank == 0:
+        arr = np.lib.format.open_memmap(path, mode="w+", dtype=np.dtype(dtype), shape=shape)
+        arr.flush()
+    _barrier()
+    if rank != 0:
+        arr = np.load(path, mmap_mode="r+")
+        if arr.shape != shape or arr.dtype != np.dtype(dtype):
+            raise ValueError(f"{path}: found {arr.dtype}{arr.shape}, expected {np.dtype(dtype)}{shape}")
+    return arr
+
+
+def shared_array_unlink(name: str, directory: str = "/dev/shm"):
+    """Remove a shared_array's backing file (collective: rank 0 unlinks after everybody is done with it)."""
+    _barrier()
+    if world()[0] == 0:
+        try:
+            os.unlink(os.path.join(directory, name))
+        except FileNotFoundError:
+            pass
+
+
+def _barrier():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.barrier()
+    except ImportError:
+        pass
+
+
+def _store(out, i, res):
+    """Write unit i's result into the caller's array(s): out is one array (n_units, ...) or a tuple of them, matching a
+    result that is one array or a tuple (None entries are skipped)."""
+    import numpy as np
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    ress = res if isinstance(res, (tuple, list)) else (res,)
+    if len(outs) != len(ress):
+        raise ValueError(f"unit {i}: {len(ress)} result arrays for {len(outs)} output arrays")
+    for o, r in zip(outs, ress):
+        if o is None or r is None:
+            continue
+        if r is not o[i] and not np.shares_memory(r, o[i]):
+            o[i][...] = r
+
+
+def run_sharded(units: Sequence, fn: Callable, gather: bool = True, dst: int = 0, lanes: int = 1, out=None):
+    """Apply `fn(unit)` to this rank's share of `units` (units that are callables are loaders: evaluated in the owning
+    rank only).
 
     gather=False: returns {unit_index: result} for the local share (results stay where they were computed).
     gather=True : rank `dst` returns the full list in unit order, the other ranks return None; results travel
-                  as host objects (numpy arrays) over gloo.
+                  as host objects (numpy arrays) over gloo -- fine for reports and small arrays.
+    out         : array (n_units, ...) or tuple of arrays that EVERY rank can write (shared_array, np.memmap): each
+                  rank stores its results in place, nothing but a barrier crosses the control plane, and every rank
+                  returns `out`.  The way to return images and flows from a multi-GPU run.
     lanes       : units kept in flight per GPU (threads with their own context); units and results must then be
                   host objects, because a DeviceArray is ordered on the stream of the context that made it.
     """
     rank, ws = world()
     mine = shard(len(units), rank, ws)
     local = _run_local(units, mine, fn, lanes)
+    if out is not None:
+        for i, res in local.items():
+            _store(out, i, res)
+        for o in (out if isinstance(out, (tuple, list)) else (out,)):
+            if hasattr(o, "flush"):
+                o.flush()
+        _barrier()
+        return out
     return _gather(local, len(units), gather, dst)
 
 
@@ -365,11 +440,15 @@ def stream_pairs(pairs, params: Optional[dict] = None, warp: bool = True, depth:
 
 
 def register_pairs(pairs: Sequence, params: Optional[dict] = None, warp: bool = False, gather: bool = True,
-                   lanes: int = 1, stream: Optional[bool] = None):
+                   lanes: int = 1, stream: Optional[bool] = None, out=None):
     """Register every (ref, mov) pair of `pairs` on this rank's GPU share.  Returns flows (and warped moving images if
     warp=True) as numpy arrays, in pair order on rank 0.
-    stream (default: on for host arrays when lanes == 1): the rank's share goes through stream_pairs -- one context,
-    transfers overlapped with the kernels -- instead of one blocking upload / compute / download per pair.
+    A pair may be a LOADER: a zero-argument callable returning (ref, mov), evaluated in the owning rank only -- and, in
+    stream mode, on the upload engine's thread, so that reading overlaps the kernels of the previous pair.
+    stream (default: on for host pairs and loaders when lanes == 1): the rank's share goes through stream_pairs -- one
+    context, transfers overlapped with the kernels -- instead of one blocking upload / compute / download per pair.
+    out: (flows, warped) arrays with one row per pair -- shared_array() or np.memmap, the same on every rank; either may
+    be None -- that the download engine fills in place; nothing is gathered then and every rank returns `out`.
     lanes > 1: the older scheme, `lanes` host threads each with a context of their own."""
     import numpy as np
     from . import OptFlowRegistrator, Warper
@@ -392,16 +471,32 @@ def register_pairs(pairs: Sequence, params: Optional[dict] = None, warp: bool = 
 
     rank, ws = world()
     mine = shard(len(pairs), rank, ws)
-    host_in = all(isinstance(pairs[i][0], np.ndarray) and isinstance(pairs[i][1], np.ndarray) for i in mine)
+    host_in = all(callable(pairs[i]) or (isinstance(pairs[i][0], np.ndarray) and isinstance(pairs[i][1], np.ndarray))
+                  for i in mine)
     if stream is None:
-        stream = lanes <= 1 and host_in and len(mine) > 1
+        stream = lanes <= 1 and host_in and (len(mine) > 1 or out is not None)
+    if out is not None and (not isinstance(out, (tuple, list)) or len(out) != 2):
+        raise ValueError("out must be a (flows, warped) pair of arrays with one row per pair (either may be None)")
     if not stream:
+        if out is not None:
+            return run_sharded(pairs, one, lanes=lanes, out=out if warp else out[0])
         return run_sharded(pairs, one, gather=gather, lanes=lanes)
     if not host_in:
-        raise ValueError("stream=True needs host (numpy) pairs")
+        raise ValueError("stream=True needs host (numpy) pairs or loaders")
     local = {}
-    for res in stream_pairs((pairs[i] for i in mine), params, warp=warp):
+    sink = None
+    if out is not None:
+        def sink(k):                                   # rows of the caller's arrays for the k-th pair of this rank
+            i = mine[k]
+            return (out[0][i] if out[0] is not None else None, out[1][i] if (warp and out[1] is not None) else None)
+    for res in stream_pairs((_unit(pairs, i) for i in mine), params, warp=warp, out=sink):
         local[mine[res.index]] = (res.flow, res.warped) if warp else res.flow
+    if out is not None:
+        for o in out:
+            if o is not None and hasattr(o, "flush"):
+                o.flush()
+        _barrier()
+        return out
     return _gather(local, len(pairs), gather)
 
 

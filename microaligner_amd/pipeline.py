@@ -8,12 +8,14 @@ normalisation, chained optical-flow registration, the overlapped page-warp drive
 memory map).
 
 Deliberately small (the control plane is not the product): one file per cycle ("Cycle N": path), one file per channel
-("Cycle N": {channel: path}, the reference's CycleBuilder form) or one (cycles, C, Z, Y, X) .npy stack of all cycles
-("CycleStack": path); images are TIFF when `tifffile` imports (read through TiffFile.series, written to a BigTIFF
-memory map, channel names taken from the OME-XML description when there is one) and `.npy` arrays otherwise or on
-request -- (C, Z, Y, X), (C, Y, X) or (Y, X) per cycle -- so the pipeline runs in images without tifffile too.  Not
-rebuilt: TIFF CycleStack inputs (they need the OME-XML's per-cycle channel layout), OME-XML rewriting, per-plane metadata
-(ome_meta_processing.py).
+("Cycle N": {channel: path}, the reference's CycleBuilder form) or one stack of all cycles ("CycleStack": path -- a
+(cycles, C, Z, Y, X) .npy, or an OME-TIFF whose channel names repeat from cycle to cycle: the cycles are cut where the
+reference channel recurs, metadata_handling.py:100-132); images are TIFF when `tifffile` imports (read through
+TiffFile.series, written to a BigTIFF memory map exactly as create_memmap_for_saving does, __main__.py:116-132) and
+`.npy` arrays otherwise or on request -- (C, Z, Y, X), (C, Y, X) or (Y, X) per cycle -- so the pipeline runs in images
+without tifffile too.  OME-XML: the description of the input is passed through to the output with its sizes and channel
+list patched (ome_passthrough) -- not the reference's full rebuild (ome_meta_processing.py: per-plane metadata, physical
+size conversion), which is control plane.
 """
 import json
 import os
@@ -114,6 +116,7 @@ class PipelineConfig:
         if "FeatureReg" not in reg and "OptFlowReg" not in reg:
             raise ValueError("Parameters for hte registration methods are absent. At least one of the registration methods: "
                              "FeatureReg or OptFlowReg must be present.")
+        self.input_ome = None               # OME-XML description of the (first) input, passed through to the outputs
         self.feature = RegParam(reg["FeatureReg"]) if "FeatureReg" in reg else None
         self.optflow = RegParam(reg["OptFlowReg"]) if "OptFlowReg" in reg else None
 
@@ -146,14 +149,14 @@ def _as_czyx(arr, what):
     return arr
 
 
-def read_stack(path):
-    """((C, Z, Y, X) array or memory map, channel names)."""
+def read_stack_meta(path):
+    """((C, Z, Y, X) array or memory map, channel names, OME-XML description or None)."""
     path = Path(path)
     if path.suffix.lower() == ".npy":
         arr = _as_czyx(np.load(path, mmap_mode="r"), str(path))
         side = path.with_suffix(".channels.json")
         names = json.load(open(side)) if side.exists() else [str(i) for i in range(arr.shape[0])]
-        return arr, names
+        return arr, names, None
     tif = _tifffile()
     if tif is None:
         raise RuntimeError(f"{path}: reading TIFF needs the `tifffile` package, which does not import here; .npy stacks "
@@ -162,22 +165,117 @@ def read_stack(path):
         series = tf.series[0]
         arr = series.asarray()
         axes = series.axes
-        names = re.findall(r'<Channel[^>]*?Name="([^"]*)"', tf.ome_metadata or "")
+        xml = tf.ome_metadata or None
+    names = channel_names_of(xml)
     order = [axes.index(a) for a in "CZYX" if a in axes]
     arr = np.transpose(arr.squeeze() if arr.ndim > len(order) else arr, order) if len(order) == arr.ndim else arr
     arr = _as_czyx(arr, str(path))
-    return arr, names if len(names) == arr.shape[0] else [str(i) for i in range(arr.shape[0])]
+    return arr, (names if len(names) == arr.shape[0] else [str(i) for i in range(arr.shape[0])]), xml
 
 
-def create_output(path, shape, dtype, fmt):
-    """Writable (1, C, Z, Y, X) memory map: BigTIFF (tifffile.memmap, __main__.py:116-132) or .npy."""
+def read_stack(path):
+    """((C, Z, Y, X) array or memory map, channel names)."""
+    return read_stack_meta(path)[:2]
+
+
+# ---- OME-XML: pass the input's description through, patched (no rebuild of ome_meta_processing.py) -------------------
+def channel_names_of(xml):
+    return re.findall(r'<Channel\b[^>]*?\bName="([^"]*)"', xml or "")
+
+
+def _xml_escape(text):
+    return (str(text).replace("&", "&amp;").replace("<", "&lt;").replace(">", "&gt;").replace('"', "&quot;"))
+
+
+def minimal_ome(shape_tczyx, dtype, names):
+    """The smallest OME-XML a reader needs to get shape, axis order and channel names back (used when the input carried
+    no description: .npy inputs written to TIFF)."""
+    T, C, Z, Y, X = (int(v) for v in shape_tczyx)
+    ptype = {"uint8": "uint8", "uint16": "uint16", "float32": "float", "int16": "int16", "uint32": "uint32"}.get(
+        np.dtype(dtype).name, np.dtype(dtype).name)
+    chans = "".join(f'<Channel ID="Channel:0:{i}" Name="{_xml_escape(n)}" SamplesPerPixel="1"/>' for i, n in enumerate(names))
+    return ('<?xml version="1.0" encoding="UTF-8"?><OME xmlns="http://www.openmicroscopy.org/Schemas/OME/2016-06">'
+            f'<Image ID="Image:0" Name="microaligner_amd"><Pixels ID="Pixels:0" DimensionOrder="XYZCT" Type="{ptype}" '
+            f'SizeX="{X}" SizeY="{Y}" SizeZ="{Z}" SizeC="{C}" SizeT="{T}">{chans}<TiffData/></Pixels></Image></OME>'
+            ).encode("ascii", "xmlcharrefreplace").decode("ascii")
+
+
+def ome_passthrough(xml, shape_tczyx, dtype, names):
+    """The input's OME-XML description for an output of `shape_tczyx` holding the channels `names` (the reference
+    regenerates the whole document, ome_meta_processing.py:455-473; here the input's document is kept -- instrument,
+    physical sizes, whatever else it carries -- and only what the registration changes is patched: SizeX/Y/Z/C/T,
+    DimensionOrder, the channel list, and the TiffData / Plane entries, which describe the input's page layout and are
+    replaced by one <TiffData/> = "pages in dimension order").  Falls back to minimal_ome without an input document."""
+    if not xml or "<Pixels" not in xml:
+        return minimal_ome(shape_tczyx, dtype, names)
+    T, C, Z, Y, X = (int(v) for v in shape_tczyx)
+    m = re.search(r"<Pixels\b[^>]*>", xml)
+    head = m.group(0)
+    self_closing = head.endswith("/>")
+    for key, val in (("SizeX", X), ("SizeY", Y), ("SizeZ", Z), ("SizeC", C), ("SizeT", T), ("DimensionOrder", "XYZCT")):
+        if re.search(rf'\b{key}="[^"]*"', head):
+            head = re.sub(rf'\b{key}="[^"]*"', f'{key}="{val}"', head)
+        else:
+            head = head[:-2 if self_closing else -1] + f' {key}="{val}"' + ("/>" if self_closing else ">")
+    # channel elements of the input, reused by name where they exist (their attributes -- Fluor, Color, wavelengths --
+    # survive), plain ones for names the input does not know
+    known = {}
+    for el in re.findall(r"<Channel\b[^>]*?(?:/>|>.*?</Channel>)", xml, flags=re.S):
+        nm = re.search(r'\bName="([^"]*)"', el)
+        if nm:
+            known.setdefault(nm.group(1), el)
+    chans = []
+    for i, n in enumerate(names):
+        el = known.get(n) or f'<Channel ID="Channel:0:{i}" Name="{_xml_escape(n)}" SamplesPerPixel="1"/>'
+        chans.append(re.sub(r'\bID="[^"]*"', f'ID="Channel:0:{i}"', el, count=1))
+    if self_closing:
+        body_start = body_end = m.end()
+        head = head[:-2] + ">"
+        tail = "</Pixels>"
+    else:
+        body_start, body_end = m.end(), xml.index("</Pixels>", m.end())
+        tail = ""
+    body = xml[body_start:body_end]
+    body = re.sub(r"<Channel\b[^>]*?(?:/>|>.*?</Channel>)", "", body, flags=re.S)
+    body = re.sub(r"<TiffData\b[^>]*?(?:/>|>.*?</TiffData>)", "", body, flags=re.S)
+    body = re.sub(r"<Plane\b[^>]*?(?:/>|>.*?</Plane>)", "", body, flags=re.S)
+    doc = xml[:m.start()] + head + "".join(chans) + "<TiffData/>" + body.strip() + tail + xml[body_end:]
+    # TIFF ImageDescription strings are 7-bit ASCII: anything else (a micro sign in a unit) becomes a character reference
+    return doc.encode("ascii", "xmlcharrefreplace").decode("ascii")
+
+
+def strip_cycle_info(name):
+    """Channel name without the cycle decoration a CycleStack carries ("c01 DAPI", "cyc2_CD3-2", ome_meta_processing.py:71-74)."""
+    name = re.sub(r"^(c|cyc|cycle)\d+(\s+|_|-)?", "", name)
+    return re.sub(r"(-\d+)?(_\d+)?$", "", name)
+
+
+def split_cycle_stack(arr, names, ref_channel):
+    """One (C_total, Z, Y, X) stack of all cycles -> [(cycle id, (C, Z, Y, X) view, channel names)]: the cycles are cut
+    where the reference channel recurs among the undecorated channel names (metadata_handling.py:100-132: channels per
+    cycle = distance between its first two occurrences)."""
+    clean = [strip_cycle_info(n) for n in names]
+    ids = [i for i, n in enumerate(clean) if re.match(ref_channel, n, re.IGNORECASE)]
+    if not ids:
+        raise ValueError(f"Incorrect reference channel {ref_channel}. Available channel names: {set(clean)}")
+    per = ids[1] - ids[0] if len(ids) > 1 else len(names)
+    if len(names) % per:
+        raise ValueError(f"CycleStack: {len(names)} channels do not divide into cycles of {per}")
+    return [(k + 1, arr[k * per:(k + 1) * per], clean[k * per:(k + 1) * per]) for k in range(len(names) // per)]
+
+
+def create_output(path, shape, dtype, fmt, description=None):
+    """Writable (1, C, Z, Y, X) memory map: BigTIFF as create_memmap_for_saving makes it (tifffile.memmap with
+    photometric minisblack, contiguous pages and the OME-XML as the description, __main__.py:116-132) or .npy."""
     path = Path(path)
     if fmt == "tif":
         tif = _tifffile()
         if tif is None:
             raise RuntimeError("writing TIFF output needs the `tifffile` package, which does not import here; set "
                                "Output: OutputFormat: npy")
-        return tif.memmap(str(path), shape=shape, dtype=dtype, bigtiff=True, metadata={"axes": "TCZYX"}), path
+        kw = dict(description=description, metadata=None) if description else dict(metadata={"axes": "TCZYX"})
+        return tif.memmap(str(path), shape=shape, dtype=dtype, photometric="minisblack", bigtiff=True, contiguous=True,
+                          **kw), path
     path = path.with_suffix(".npy")
     return np.lib.format.open_memmap(str(path), mode="w+", dtype=dtype, shape=shape), path
 
@@ -199,8 +297,9 @@ def _load_cycles(cfg):
         # layout of the OME-XML, which is not rebuilt
         path = cfg.paths[0]
         if path.suffix.lower() != ".npy":
-            raise NotImplementedError("a TIFF stack of all cycles needs the per-cycle channel layout of its OME-XML, which "
-                                      "is not rebuilt; give one stack per cycle, or a (cycles, C, Z, Y, X) .npy")
+            arr, names, xml = read_stack_meta(path)
+            cfg.input_ome = xml
+            return split_cycle_stack(arr, names, cfg.ref_channel)
         arr = np.load(path, mmap_mode="r")
         if arr.ndim != 5:
             raise ValueError(f"{path}: a CycleStack .npy must be (cycles, C, Z, Y, X), got shape {arr.shape}")
@@ -220,7 +319,13 @@ def _load_cycles(cfg):
                 stack[c, :pl.shape[0]] = pl
             out.append((cyc, stack, list(chans)))
         return out
-    return [(cyc,) + read_stack(p) for cyc, p in sorted(cfg.paths.items())]
+    out = []
+    for cyc, p in sorted(cfg.paths.items()):
+        arr, names, xml = read_stack_meta(p)
+        if getattr(cfg, "input_ome", None) is None:
+            cfg.input_ome = xml              # the first cycle's description is the one passed through to the outputs
+        out.append((cyc, arr, names))
+    return out
 
 
 def run_feature_reg(cfg, cycles, log=print):
@@ -300,17 +405,24 @@ def _writer(cfg, cycles, stage, fmt):
     C0, zmax = cycles[0][1].shape[0], max(a.shape[1] for _, a, _ in cycles)
     H, W, dtype = cycles[0][1].shape[2], cycles[0][1].shape[3], cycles[0][1].dtype
     written, state = [], {}
+    xml = getattr(cfg, "input_ome", None)
+    names_of = {cyc: names for cyc, _, names in cycles}
     if cfg.to_stack:
         total_c = sum(a.shape[0] for _, a, _ in cycles)
-        state["mm"], p = create_output(cfg.out_dir / f"{cfg.out_prefix}{stage}_result_stack.tif", (1, total_c, zmax, H, W), dtype, fmt)
+        shape = (1, total_c, zmax, H, W)
+        # channel names of the stack carry their cycle, as the reference's do ("c01 DAPI", stack_builder.py:124-134)
+        all_names = [f"c{cyc:02d} {strip_cycle_info(n)}" for cyc, _, names in cycles for n in names]
+        desc = ome_passthrough(xml, shape, dtype, all_names) if fmt == "tif" else None
+        state["mm"], p = create_output(cfg.out_dir / f"{cfg.out_prefix}{stage}_result_stack.tif", shape, dtype, fmt, desc)
         written.append(p)
 
     def dst(n, cyc, arr):
         if cfg.to_stack:
             c0 = n * C0                               # cross-cycle channel id as the reference computes it (:415,429)
             return state["mm"][0, c0:c0 + arr.shape[0], :arr.shape[1]]
-        mm, p = create_output(cfg.out_dir / f"{cfg.out_prefix}{stage}_result_cyc{cyc:03d}.tif", (1, arr.shape[0], zmax, H, W),
-                              dtype, fmt)
+        shape = (1, arr.shape[0], zmax, H, W)
+        desc = ome_passthrough(xml, shape, dtype, names_of[cyc]) if fmt == "tif" else None
+        mm, p = create_output(cfg.out_dir / f"{cfg.out_prefix}{stage}_result_cyc{cyc:03d}.tif", shape, dtype, fmt, desc)
         written.append(p)
         state[cyc] = mm
         return mm[0, :, :arr.shape[1]]

@@ -38,6 +38,23 @@ def main(out_path):
     assert sorted(local) == parallel.shard(len(pairs), rank, ws)
     assert n_calls == len(parallel.shard(len(pairs), rank, ws))
 
+    # results in place: every rank writes its flows into a node-wide shared array; units are loaders, evaluated by their
+    # owner only; nothing is gathered
+    loaded = []
+
+    def loader(k):
+        def load():
+            loaded.append(k)
+            return pairs[k]
+        return load
+
+    store = parallel.shared_array(f"ma_test_{os.environ['MASTER_PORT']}", (len(pairs), 210, 220, 2), np.float32)
+    got = parallel.run_sharded([loader(k) for k in range(len(pairs))], compute, out=store)
+    assert got is store and sorted(loaded) == parallel.shard(len(pairs), rank, ws)
+    shared_ok = all(np.array_equal(store[k], compute(pairs[k])) for k in range(len(pairs)))   # every rank sees every row
+    parallel.shared_array_unlink(f"ma_test_{os.environ['MASTER_PORT']}")
+    assert shared_ok
+
     # timing reduction used by bench.py: max over ranks
     import torch
     t = torch.tensor([1.0 + rank], dtype=torch.float64)

@@ -73,6 +73,10 @@ def test_bench_eight_ranks_report_per_rank_rows_and_deal_pairs_round_robin():
     assert res["n_gpus"] == 8 and res["config"]["pairs_per_step"] == 64
     assert [row["rank"] for row in res["ranks"]] == list(range(8))
     assert [row["pairs"] for row in res["ranks"]] == [list(range(r0, 64, 8)) for r0 in range(8)]
+    # the data plane: every unit was loaded by the rank that owns it and by nobody else, and its result reached the
+    # node-wide shared array without passing through the control plane
+    assert [row["units_loaded"] for row in res["ranks"]] == [list(range(r0, 64, 8)) for r0 in range(8)]
+    assert res["shared_results_ok"] is True and "shared memory" in res["results_via"]
     per = [row["ms_per_step"] for row in res["ranks"]]
     assert res["rank_ms_per_step"] == {"min": min(per), "mean": sum(per) / 8, "max": max(per)}
     assert abs(res["ms_per_step"] - max(per)) < 1e-9            # the headline time is the slowest rank's

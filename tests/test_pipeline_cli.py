@@ -135,3 +135,94 @@ def test_cli_runs_the_cycle_chain_like_the_oracle_pipeline(tmp_path):
         for c in range(2):
             for z in range(2):
                 assert np.array_equal(out[0, 2 * k + c, z], RO.warp(cycles[k][c, z], flow, 150, 30)), (k, c, z)
+
+
+def _python_with_tifffile():
+    """An interpreter that imports tifffile and numpy: this one, or the image's conda python (tifffile 2021.7.2)."""
+    import shutil
+    for exe in (sys.executable, "/opt/conda/bin/python3.9", shutil.which("python3.9")):
+        if exe and os.path.exists(exe):
+            r = subprocess.run([exe, "-c", "import tifffile, numpy, yaml"], capture_output=True)
+            if r.returncode == 0:
+                return exe
+    return None
+
+
+def test_tiff_branch_round_trips_real_files(tmp_path):
+    """The TIFF branch of the pipeline under an interpreter that has tifffile: OME-TIFF in through
+    read_stack, BigTIFF memory map out as create_memmap_for_saving makes it (__main__.py:116-132) with the input's OME-XML
+    passed through (sizes and channel list patched), a TIFF CycleStack cut into cycles where the reference channel recurs
+    (metadata_handling.py:100-132), the writer of run().  tests/_tiff_roundtrip.py does the work and prints one JSON line."""
+    exe = _python_with_tifffile()
+    if exe is None:
+        pytest.skip("no interpreter with tifffile in this image")
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "_tiff_roundtrip.py"), str(tmp_path)], capture_output=True, text=True,
+                       cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = __import__("json").loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["ok"] is True and "create_output BigTIFF memmap + OME passthrough" in res["checked"]
+
+
+def test_ome_passthrough_patches_only_what_registration_changes():
+    xml = ('<?xml version="1.0" encoding="UTF-8"?><OME xmlns="http://www.openmicroscopy.org/Schemas/OME/2016-06">'
+           '<Instrument ID="Instrument:0"/><Image ID="Image:0" Name="x"><Pixels ID="Pixels:0" DimensionOrder="XYCZT" '
+           'Type="uint16" SizeX="10" SizeY="20" SizeZ="1" SizeC="2" SizeT="1" PhysicalSizeX="0.325" PhysicalSizeXUnit="µm">'
+           '<Channel ID="Channel:0:0" Name="DAPI" Fluor="Hoechst" SamplesPerPixel="1"><LightPath/></Channel>'
+           '<Channel ID="Channel:0:1" Name="CD3" SamplesPerPixel="1"/><TiffData IFD="0" PlaneCount="1"/>'
+           '<TiffData IFD="1" PlaneCount="1"/><Plane TheC="0" TheZ="0" TheT="0"/></Pixels></Image></OME>')
+    out = P.ome_passthrough(xml, (1, 4, 3, 50, 60), np.uint16, ["c01 DAPI", "c01 CD3", "DAPI", "new"])
+    for frag in ('SizeX="60"', 'SizeY="50"', 'SizeZ="3"', 'SizeC="4"', 'SizeT="1"', 'DimensionOrder="XYZCT"', 'PhysicalSizeX="0.325"',
+                 '<Instrument ID="Instrument:0"/>', '&#181;m'):
+        assert frag in out, frag
+    assert out.count("<TiffData") == 1 and "<Plane" not in out and out.isascii()
+    assert P.channel_names_of(out) == ["c01 DAPI", "c01 CD3", "DAPI", "new"]
+    assert 'ID="Channel:0:2" Name="DAPI" Fluor="Hoechst"' in out and "<LightPath/>" in out     # a known channel keeps its attributes
+    assert [P.strip_cycle_info(n) for n in ("c01 DAPI", "cyc2_CD3-2", "cycle3-CD8_1", "DAPI")] == ["DAPI", "CD3", "CD8", "DAPI"]
+    mini = P.ome_passthrough(None, (1, 2, 1, 5, 6), np.float32, ["a", "b"])
+    assert 'Type="float"' in mini and 'SizeC="2"' in mini and P.channel_names_of(mini) == ["a", "b"]
+
+
+@pytest.mark.gpu
+def test_cli_with_tiff_inputs_and_outputs_equals_the_npy_run(tmp_path):
+    """`python -m microaligner_amd config.yaml` with OME-TIFF cycles in and a BigTIFF stack out (under the interpreter that
+    has tifffile) writes the very pixels of the .npy run of the same data -- which
+    test_cli_runs_the_cycle_chain_like_the_oracle_pipeline holds against the oracle pipeline -- and an OME-XML with the
+    stack's sizes and cycle-decorated channel names."""
+    exe = _python_with_tifffile()
+    if exe is None:
+        pytest.skip("no interpreter with tifffile in this image")
+    H, W = 420, 380
+    names = ["DAPI", "CD3"]
+    paths_npy, paths_tif = {}, {}
+    for k in range(3):
+        ref, mov = synthetic.make_pair(H, W, seed=40 + k, dtype=np.uint16)
+        base = ref if k == 0 else mov
+        stack = np.stack([np.stack([base, (base // 2).astype(np.uint16)]), np.stack([(base // 3).astype(np.uint16), base[::-1].copy()])])
+        np.save(tmp_path / f"cyc{k + 1}.npy", stack)
+        (tmp_path / f"cyc{k + 1}.channels.json").write_text('["DAPI", "CD3"]')
+        paths_npy[f"Cycle {k + 1}"] = str(tmp_path / f"cyc{k + 1}.npy")
+        paths_tif[f"Cycle {k + 1}"] = str(tmp_path / f"cyc{k + 1}.ome.tif")
+    conv = ("import sys, numpy as np, tifffile\n"
+            "for k in (1, 2, 3):\n"
+            f"    a = np.load(r'{tmp_path}/cyc%d.npy' % k)\n"
+            f"    tifffile.imwrite(r'{tmp_path}/cyc%d.ome.tif' % k, a[None], bigtiff=True, photometric='minisblack',\n"
+            "                     metadata={'axes': 'TCZYX', 'Channel': {'Name': ['DAPI', 'CD3']}})\n")
+    assert subprocess.run([exe, "-c", conv], capture_output=True, text=True).returncode == 0
+    (tmp_path / "npy").mkdir()
+    (tmp_path / "tif").mkdir()
+    cfg_npy = config(tmp_path / "npy", paths_npy, Input__ReferenceChannel="DAPI")
+    cfg_tif = config(tmp_path / "tif", paths_tif, Input__ReferenceChannel="DAPI")
+    for cfg in (cfg_npy, cfg_tif):
+        r = subprocess.run([exe, "-m", "microaligner_amd", str(cfg)], capture_output=True, text=True, cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    check = ("import sys, json, numpy as np, tifffile\n"
+             f"a = np.load(r'{tmp_path}/npy/out/exp_optflow_reg_result_stack.npy')\n"
+             f"tf = tifffile.TiffFile(r'{tmp_path}/tif/out/exp_optflow_reg_result_stack.tif')\n"
+             "b = tf.series[0].asarray().reshape(a.shape)\n"
+             "print(json.dumps({'equal': bool(np.array_equal(a, b)), 'bigtiff': bool(tf.is_bigtiff), 'ome': tf.ome_metadata}))\n")
+    r = subprocess.run([exe, "-c", check], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = __import__("json").loads(r.stdout.strip().splitlines()[-1])
+    assert res["equal"] and res["bigtiff"]
+    assert P.channel_names_of(res["ome"]) == [f"c{c:02d} {n}" for c in (1, 2, 3) for n in names]
+    assert 'SizeC="6"' in res["ome"] and 'SizeZ="2"' in res["ome"]
