@@ -176,6 +176,22 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
     return out
 
 
+def cpu_ranges(cpus):
+    """[0, 1, 2, 8, 9] -> "0-2,8-9" (the sysfs cpulist notation)."""
+    out, start, prev = [], None, None
+    for c in sorted(cpus):
+        if start is None:
+            start = prev = c
+        elif c == prev + 1:
+            prev = c
+        else:
+            out.append(f"{start}-{prev}" if prev > start else str(start))
+            start = prev = c
+    if start is not None:
+        out.append(f"{start}-{prev}" if prev > start else str(start))
+    return ",".join(out)
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -661,7 +677,7 @@ def main():
     rows = rank_table(dist, world, rank, {
         "rank": rank, "device": dev_index, "pci_bus_id": info["pci_bus_id"], "name": info["name"],
         "hbm_free_gb": round(info["mem_free"] / 2 ** 30, 1), "hbm_total_gb": round(info["mem_total"] / 2 ** 30, 1),
-        "cpus": (f"{bound_cpus[0]}-{bound_cpus[-1]} ({len(bound_cpus)} of {len(all_cpus)}, local to the device)"
+        "cpus": (f"{cpu_ranges(bound_cpus)} ({len(bound_cpus)} of {len(all_cpus)}, local to the device)"
                  if bound_cpus else f"all {len(all_cpus)} (no NUMA binding: topology unknown or single node)"),
         "pairs": my_pairs, "ms_per_step": round((t1 - t0) / args.steps * 1e3, 3), "clock_ghz": round(clock_ghz, 3),
         "result": summary})
