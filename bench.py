@@ -32,8 +32,9 @@ NOMINAL_GHZ = 2.4      # MI355X_MICROARCH.md, chip-level parameters
 # FP32 vector peak for the NON-fused arithmetic of the window blurs and the DOG (one flop per lane and instruction
 # slot: v_pk_add / v_pk_mul): 256 CUs x 4 SIMDs x 32 lanes per clock = 78.6 TFLOP/s at 2.4 GHz -- half of the 157.3
 # TFLOP/s the data sheet quotes for fused multiply-adds.  The chip does not hold 2.4 GHz in these kernels (it is power
-# limited: profiles/r03_notes.md); ma_clock_probe measures the clock it sustains under the same instruction mix in the
-# same run, and `frac` is taken against the peak at THAT clock, the nominal one is reported beside it.
+# limited: profiles/r03_notes.md); `frac` is taken against the NOMINAL peak; ma_clock_probe measures the clock the chip
+# sustains under the same instruction mix in the same run, and the fraction of the peak at THAT clock is reported beside it
+# (`frac_at_sustained_clock`).
 VALU_LANES_PER_CLOCK = 256 * 4 * 32
 VALU_BOUND = ("blur_v", "blur_h_solve", "dog")
 
@@ -162,12 +163,15 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
         # chip sustains under this instruction mix (ma_clock_probe, same run); the HBM view stays in `hbm`
         fpp = valu_flops_per_px(name, winsize_taps, fused, iters)
         tf = fpp * rec["px"] / sec / 1e12
-        # the clock this very kernel held (rocprofv3 summary of the loaded kernels) when there is one, else the probe's
+        # headline: against the NOMINAL peak (256 CUs x 4 SIMD-32 at 2.4 GHz, MI355X_MICROARCH.md); beside it the same
+        # against the peak at the clock this very kernel held (rocprofv3 summary of the loaded kernels) or, failing that, the
+        # clock ma_clock_probe sustained in this run -- the chip is power limited in these kernels (profiles/r03_notes.md)
         ghz = kernel_clock or clock_ghz or NOMINAL_GHZ
-        peak = VALU_LANES_PER_CLOCK * ghz * 1e9 / 1e12
-        out.update({"bound": "valu", "achieved": round(tf, 2), "peak": round(peak, 2), "unit": "TFLOP/s",
-                    "frac": round(tf / peak, 4), "peak_nominal": round(VALU_LANES_PER_CLOCK * NOMINAL_GHZ * 1e9 / 1e12, 2),
-                    "frac_of_nominal": round(tf / (VALU_LANES_PER_CLOCK * NOMINAL_GHZ * 1e9 / 1e12), 4),
+        peak_nom = VALU_LANES_PER_CLOCK * NOMINAL_GHZ * 1e9 / 1e12
+        peak_clk = VALU_LANES_PER_CLOCK * ghz * 1e9 / 1e12
+        out.update({"bound": "valu", "achieved": round(tf, 2), "peak": round(peak_nom, 2), "unit": "TFLOP/s",
+                    "frac": round(tf / peak_nom, 4),
+                    "peak_at_sustained_clock": round(peak_clk, 2), "frac_at_sustained_clock": round(tf / peak_clk, 4),
                     "clock_ghz": round(ghz, 3),
                     "clock_source": (f"{kernel_clock_source} (GRBM_GUI_ACTIVE of this kernel)" if kernel_clock else
                                      "ma_clock_probe, same run" if clock_ghz else "nominal"),

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Effective shader clock per kernel: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / dispatch duration, dispatches of
-# >= 0.3 ms only (MI355X_MICROARCH.md, DVFS section).  bash tools/kernel_clock.sh <tag> [bench args]
+# >= 0.3 ms only (MI355X_MICROARCH.md, DVFS section), companion stream off (every kernel alone on the chip).
+# bash tools/kernel_clock.sh <tag> [bench args]
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 TAG=${1:-clk}; shift
 OUT=gpurun_out/clock_$TAG
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc GRBM_GUI_ACTIVE -d $OUT/p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-variants "$@" > /dev/null 2> $OUT/err
+rocprofv3 --pmc GRBM_GUI_ACTIVE -d $OUT/p --output-format csv -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-variants --no-companion "$@" > /dev/null 2> $OUT/err
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections, re
 acc = collections.defaultdict(lambda: [0, 0.0, 0.0])
