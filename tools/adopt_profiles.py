@@ -22,8 +22,9 @@ traffic = json.load(open(os.path.join(src, f"{tag}_hbm_traffic_cfg3.json")))
 want = build.source_hash()
 if traffic.get("kernel_source_hash") != want:
     sys.exit(f"the summaries were collected with kernel sources {traffic.get('kernel_source_hash')}, this tree is {want}")
-for name in (f"{tag}_kernel_stats_cfg3.csv", f"{tag}_hbm_traffic_cfg3.json"):
-    shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", name))
+for name in (f"{tag}_kernel_stats_cfg3.csv", f"{tag}_kernel_stats_cfg3_companion_on.csv", f"{tag}_hbm_traffic_cfg3.json"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", name))
 # the GPU box has no .git: the commit the measured tree descends from is recorded here, at adoption
 import subprocess
 head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()

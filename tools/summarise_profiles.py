@@ -31,15 +31,24 @@ def newest(pattern):
     return max(glob.glob(pattern), key=os.path.getmtime)
 
 
-# 1. kernel stats (rocprofv3 --kernel-trace --stats)
-stats = newest(os.path.join(out, "kt", "*", "*_kernel_stats.csv"))
-rows = list(csv.DictReader(open(stats)))
-with open(os.path.join(prof, f"{tag}_kernel_stats_cfg3.csv"), "w") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
-    for r in rows:
-        w.writerow([short(r["Name"]), r["Calls"], f"{float(r['TotalDurationNs']) / 1e6:.3f}",
-                    f"{float(r['AverageNs']) / 1e3:.2f}", r["Percentage"]])
+# 1. kernel stats (rocprofv3 --kernel-trace --stats): companion stream off (every kernel alone on the chip: the numbers
+#    that are comparable from round to round) and, when collected, the default command (companion on: what bench.py's own
+#    per-kernel events see in the default run)
+def write_stats(sub, name):
+    found = glob.glob(os.path.join(out, sub, "*", "*_kernel_stats.csv"))
+    if not found:
+        return
+    rows = list(csv.DictReader(open(max(found, key=os.path.getmtime))))
+    with open(os.path.join(prof, name), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_us", "percent"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], f"{float(r['TotalDurationNs']) / 1e6:.3f}",
+                        f"{float(r['AverageNs']) / 1e3:.2f}", r["Percentage"]])
+
+
+write_stats("kt", f"{tag}_kernel_stats_cfg3.csv")
+write_stats("kt_on", f"{tag}_kernel_stats_cfg3_companion_on.csv")
 
 # 2. HBM traffic per kernel (separate --pmc passes; FETCH_SIZE is doubled per MI355X_MICROARCH.md, HBM section)
 tot = {}
@@ -65,7 +74,8 @@ steps = 3  # --steps 2 --warmup 1
 sys.path.insert(0, root)
 from microaligner_amd import _lib  # noqa: E402
 json.dump({"kernel_source_hash": _lib.source_hash(), "library": _lib.load().ma_version().decode(),
-           "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants (cfg3)", "steps_profiled": steps,
+           "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-variants --no-companion (cfg3)",
+           "steps_profiled": steps,
            "note": "FETCH_SIZE*2 + WRITE_SIZE (KiB -> bytes), per MI355X_MICROARCH.md HBM section; separate --pmc passes",
            "per_kernel": traffic,
            "per_bench_group_bytes_per_step": {g: v["hbm_bytes"] / steps for g, v in groups.items()}},
