@@ -740,26 +740,35 @@ def main():
             "results_to_shared_array_ms": round(shared_ms, 1) if shared_ms is not None else None,
             "results_to_shared_array": shared_note,
         }
-        if keep_host and not args.fused:
-            res["variants"] = {}
-            dref, dmov, inv_affine, _ = work[0]
-            # informational: the drop-in API as the reference's callers use it, numpy in -> numpy out (PCIe inclusive;
-            # never the headline value)
-            th = host_inclusive_leg(max(1, min(args.steps, 3)), ref, mov if inv_affine is None else
-                                    ctx.warp_affine(dmov, inv_affine).numpy(), params)
-            res["variants"]["host_inclusive"] = {"value": round(H * W / th / 1e6, 2), "unit": "Mpix/s",
-                                                 "ms_per_step": round(th * 1e3, 3),
-                                                 "what": "numpy in -> numpy out, ONE pair, the reference's statements: H2D of ref and mov, register(), "
-                                                         "D2H of the flow, Warper.warp(mov, flow) (the flow register() returned is recognised as "
-                                                         "resident; the caller's writable mov array is uploaded again), D2H of the warped image; "
-                                                         "nothing overlaps: see host_stream for the sustained rate"}
+        def informational(store, name, fn):
+            """An informational leg never costs the headline line: a failure is recorded in its place."""
+            try:
+                store[name] = fn()
+            except Exception as e:   # noqa: BLE001
+                import traceback
+                store[name] = {"error": repr(e), "where": traceback.format_exc().strip().splitlines()[-3:]}
 
+        if keep_host and not args.fused:
+            V = res["variants"] = {}
+            dref, dmov, inv_affine, _ = work[0]
+
+            def leg_host_inclusive():
+                # the drop-in API as the reference's callers use it, numpy in -> numpy out (PCIe inclusive)
+                th = host_inclusive_leg(max(1, min(args.steps, 3)), ref, mov if inv_affine is None else
+                                        ctx.warp_affine(dmov, inv_affine).numpy(), params)
+                return {"value": round(H * W / th / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(th * 1e3, 3),
+                        "what": "numpy in -> numpy out, ONE pair, the reference's statements: H2D of ref and mov, register(), "
+                                "D2H of the flow, Warper.warp(mov, flow) (the flow register() returned is recognised as "
+                                "resident; the caller's writable mov array is uploaded again), D2H of the warped image; "
+                                "nothing overlaps: see host_stream for the sustained rate"}
+
+            informational(V, "host_inclusive", leg_host_inclusive)
             if args.stream_pairs > 0 and inv_affine is None:
-                # informational: the sustained numpy -> numpy rate over a stream of distinct pairs (PCIe inclusive; never
-                # the headline value), in the workload's dtype and in the pipeline-faithful uint8
-                res["variants"]["host_stream"] = host_stream_leg(args.stream_pairs, ref, mov, params, np_dtype)
+                # the sustained numpy -> numpy rate over a stream of distinct pairs (PCIe inclusive; never the headline
+                # value), in the workload's dtype and in the pipeline-faithful uint8
+                informational(V, "host_stream", lambda: host_stream_leg(args.stream_pairs, ref, mov, params, np_dtype))
                 if np_dtype != np.uint8:
-                    res["variants"]["host_stream_u8"] = host_stream_leg(args.stream_pairs, ref, mov, params, np.uint8)
+                    informational(V, "host_stream_u8", lambda: host_stream_leg(args.stream_pairs, ref, mov, params, np.uint8))
             if freg is None:
                 del ref, mov
 
@@ -772,32 +781,42 @@ def main():
                 ctx.sync()
                 return (time.perf_counter() - tf0) / args.steps
 
-            # informational: the same workload with the window blur in the FMA rounding model
-            # (MA_FB_MULADD_FUSED: OpenCV builds whose v_muladd is a fused multiply-add); not the headline value
-            reg.muladd_fused = True
-            tf = timed_steps()
-            reg.muladd_fused = False
-            res["variants"]["muladd_fma"] = {"value": round(H * W / tf / 1e6, 2), "unit": "Mpix/s",
-                                             "ms_per_step": round(tf * 1e3, 3)}
-            if reg.use_dog and not args.dog_fused:
-                # informational: the dog() chain in the rounding model of OpenCV's AVX2 + FMA3 objects
+            def leg_muladd_fma():
+                # the same workload with the window blur in the FMA rounding model (MA_FB_MULADD_FUSED: OpenCV builds whose
+                # v_muladd is a fused multiply-add)
+                reg.muladd_fused = True
+                try:
+                    tf = timed_steps()
+                finally:
+                    reg.muladd_fused = False
+                return {"value": round(H * W / tf / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(tf * 1e3, 3)}
+
+            def leg_dog_fma():
+                # the dog() chain in the rounding model of OpenCV's AVX2 + FMA3 objects
                 reg.dog_muladd_fused = True
-                td = timed_steps()
-                reg.dog_muladd_fused = False
-                res["variants"]["dog_fma"] = {"value": round(H * W / td / 1e6, 2), "unit": "Mpix/s",
-                                              "ms_per_step": round(td * 1e3, 3),
-                                              "what": "dog() with fused multiply-adds (MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE)"}
-            if args.lanes > 1 and inv_affine is None:
-                # informational: `lanes` independent pairs in flight on this GPU, one context (HIP stream, workspace)
-                # and one host thread per lane -- what parallel.register_pairs(lanes=...) does for a list of pairs
+                try:
+                    td = timed_steps()
+                finally:
+                    reg.dog_muladd_fused = False
+                return {"value": round(H * W / td / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(td * 1e3, 3),
+                        "what": "dog() with fused multiply-adds (MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE)"}
+
+            def leg_lanes():
+                # `lanes` independent pairs in flight on this GPU, one context (HIP stream, workspace) and one host thread
+                # per lane -- what parallel.register_pairs(lanes=...) does for a list of device-resident pairs
                 tl = lanes_leg(args.lanes, args.steps, ctx.device, dref, dmov, params, reg.tile_size, reg.overlap)
-                res["variants"][f"lanes{args.lanes}"] = {
-                    "value": round(H * W / tl / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(tl * 1e3, 3),
-                    "pairs_in_flight": args.lanes}
+                return {"value": round(H * W / tl / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(tl * 1e3, 3),
+                        "pairs_in_flight": args.lanes}
+
+            informational(V, "muladd_fma", leg_muladd_fma)
+            if reg.use_dog and not args.dog_fused:
+                informational(V, "dog_fma", leg_dog_fma)
+            if args.lanes > 1 and inv_affine is None:
+                informational(V, f"lanes{args.lanes}", leg_lanes)
         if world == 1 and not args.no_cpu_baseline and not args.pairs_total:
             set_affinity(all_cpus)      # the CPU baseline uses every core of the host, not just the GPU's node
             sample = args.cpu_sample or (H if (os.cpu_count() or 1) >= 128 else 4096)
-            res["cpu_baseline"] = cpu_baseline(min(sample, H), params)
+            informational(res, "cpu_baseline", lambda: cpu_baseline(min(sample, H), params))
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
