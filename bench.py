@@ -509,7 +509,7 @@ def main():
         n_units = pairs_per_step
         loaded = []
         name = f"ma_bench_dry_{os.environ.get('MASTER_PORT', os.getpid())}"
-        store = parallel.shared_array(name, (n_units, 4, 8), np.float32)
+        store = parallel.shared_array(name, (n_units, 4, 8), np.float32, unlink=True)
 
         def loader(i):
             def load():
@@ -522,7 +522,6 @@ def main():
         shared_ok = bool(all(np.all(store[i] == 1000 * (i % world) + i) for i in range(n_units)))
         rows = rank_table(dist, world, rank, {"rank": rank, "ms_per_step": mine / args.steps * 1e3, "pairs": my_pairs,
                                                "device": None, "pci_bus_id": None, "units_loaded": sorted(loaded)})
-        parallel.shared_array_unlink(name)
         if rank == 0:
             per = [r["ms_per_step"] for r in rows]
             print(json.dumps({"metric": METRIC, "value": None, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -664,8 +663,9 @@ def main():
         go = -reduce_max(-(1.0 if (rank != 0 or room > 1.2 * need) else 0.0)) > 0.5
         if go:
             ts0 = time.perf_counter()
-            flows = parallel.shared_array(name + "_flow", (world, H, W, 2), np.float32)
-            warps = parallel.shared_array(name + "_warp", (world, H, W), np_dtype)
+            # (unlink=True: the names are gone once every rank has mapped them -- nothing can be left in /dev/shm)
+            flows = parallel.shared_array(name + "_flow", (world, H, W, 2), np.float32, unlink=True)
+            warps = parallel.shared_array(name + "_warp", (world, H, W), np_dtype, unlink=True)
             out[0].numpy(out=flows[rank])
             out[1].numpy(out=warps[rank])
             dist.barrier()
@@ -673,8 +673,6 @@ def main():
             if rank == 0:   # every rank's rows arrived: a strided sample per rank, next to what the rank reports over gloo
                 shared_note = [float(flows[r][::997, ::991].sum()) for r in range(world)]
             del flows, warps
-            parallel.shared_array_unlink(name + "_flow")
-            parallel.shared_array_unlink(name + "_warp")
         else:
             shared_note = f"skipped: /dev/shm has {room / 2 ** 30:.0f} GiB free, {need / 2 ** 30:.0f} GiB needed"
     info = device_info(dev_index)

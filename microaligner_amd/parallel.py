@@ -102,12 +102,15 @@ def _run_local(units: Sequence, mine: List[int], fn: Callable, lanes: int):
     return results
 
 
-def shared_array(name: str, shape, dtype, directory: str = "/dev/shm"):
+def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: bool = False):
     """A node-wide array every rank maps: rank 0 creates `directory/name` (POSIX shared memory by default; any path
     works, e.g. next to the output TIFF), the others open it after a barrier.  COLLECTIVE (every rank calls it with
     the same arguments).  This is where results of a sharded run go instead of being pickled through the control plane:
     each rank's download engine writes its rows in place (run_sharded / register_pairs `out=`), the way the reference
-    writes every page straight into its memmapped output (__main__.py:116-132).  Remove it with shared_array_unlink."""
+    writes every page straight into its memmapped output (__main__.py:116-132).
+    unlink=True: the name is removed as soon as every rank has mapped the file -- the mappings stay valid, the memory goes
+    back when the last rank drops its array or dies, and nothing is left behind in /dev/shm whatever happens later (use it
+    for scratch results; keep the name, and remove it with shared_array_unlink, when another process is to open it)."""
     import numpy as np
     rank, ws = world()
     path = os.path.join(directory, name)
@@ -120,6 +123,10 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm"):
         arr = np.load(path, mmap_mode="r+")
         if arr.shape != shape or arr.dtype != np.dtype(dtype):
             raise ValueError(f"{path}: found {arr.dtype}{arr.shape}, expected {np.dtype(dtype)}{shape}")
+    if unlink:
+        _barrier()
+        if rank == 0:
+            os.unlink(path)
     return arr
 
 
