@@ -572,9 +572,19 @@ def test_stream_pairs_equals_the_one_pair_path_and_moves_every_byte_once(ctx):
     for r in parallel.stream_pairs(pairs[:4], params, warp=False, out=lambda i: (dst[i], None)):
         assert r.warped is None
     assert all(np.array_equal(dst[i], single[i][0]) for i in range(4))
-    # register_pairs routes host pairs through the stream
+    # register_pairs routes host pairs through the stream; loaders are evaluated lazily; out= rows are filled in place
     flows = parallel.register_pairs(pairs[:4], params, warp=True)
     assert all(np.array_equal(f, single[i][0]) and np.array_equal(w_, single[i][1]) for i, (f, w_) in enumerate(flows))
+    called = []
+    loaders = [(lambda k=k: (called.append(k), pairs[k])[1]) for k in range(4)]
+    store = (np.zeros((4, 700, 900, 2), np.float32), np.zeros((4, 700, 900), np.float32))
+    assert parallel.register_pairs(loaders, params, warp=True, out=store) is store and called == [0, 1, 2, 3]
+    assert all(np.array_equal(store[0][i], single[i][0]) and np.array_equal(store[1][i], single[i][1]) for i in range(4))
+    # the engine entry points reject what they cannot serve
+    with pytest.raises(ValueError):
+        ctx.engine_sync(7)
+    with pytest.raises(ValueError):
+        ctx.engine_upload(ctx.empty((10,), np.float32), np.zeros(11, np.float32))
 
 
 def test_companion_stream_switch_changes_nothing_but_the_schedule(ctx):

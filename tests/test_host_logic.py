@@ -374,3 +374,42 @@ def test_nmi_of_raw_labels_is_scikit_learns():
             assert abs(_nmi_of_labels(a, a) - 1.0) < 1e-14
         z = np.zeros(9)
         assert _nmi_of_labels(z, z) == 1.0 == nmi(z, z) and _nmi_of_labels(z, np.arange(9.0)) == 0.0 == nmi(z, np.arange(9.0))
+
+
+def test_numa_binding_follows_the_devices_local_cpulist(tmp_path):
+    """device.bind_to_device_numa: the CPUs of /sys/bus/pci/devices/<bdf>/local_cpulist, for every thread of the process;
+    nothing happens when the topology is unknown, when the list is the whole machine, or when MICROALIGNER_BIND_NUMA=0."""
+    import os
+    import threading
+    from microaligner_amd import device
+    assert device._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and device._parse_cpulist("") == []
+    before = os.sched_getaffinity(0)
+    if len(before) < 2:
+        pytest.skip("needs at least two CPUs")
+    some = sorted(before)[:max(1, len(before) // 2)]
+    bdf = tmp_path / "0000:c1:00.0"
+    bdf.mkdir()
+    (bdf / "local_cpulist").write_text(",".join(str(c) for c in some) + "\n")
+    assert device.device_local_cpus(pci_bus_id="0000:C1:00.0", sysfs=str(tmp_path)) == some
+    assert device.device_local_cpus(pci_bus_id="0000:ff:00.0", sysfs=str(tmp_path)) == []
+    seen = {}
+    stop = threading.Event()
+    t = threading.Thread(target=lambda: (stop.wait(5), seen.update(mask=os.sched_getaffinity(0))))
+    t.start()                                  # a thread that exists BEFORE the binding is moved as well
+    try:
+        os.environ["MICROALIGNER_BIND_NUMA"] = "0"
+        assert device.bind_to_device_numa(pci_bus_id="0000:c1:00.0", sysfs=str(tmp_path)) == [] and os.sched_getaffinity(0) == before
+        del os.environ["MICROALIGNER_BIND_NUMA"]
+        assert device.bind_to_device_numa(pci_bus_id="0000:ff:00.0", sysfs=str(tmp_path)) == []
+        assert device.bind_to_device_numa(pci_bus_id="0000:c1:00.0", sysfs=str(tmp_path)) == some
+        assert os.sched_getaffinity(0) == set(some)
+        stop.set()
+        t.join()
+        assert seen["mask"] == set(some)
+        (bdf / "local_cpulist").write_text(",".join(str(c) for c in sorted(some)) + "\n")
+        assert device.bind_to_device_numa(pci_bus_id="0000:c1:00.0", sysfs=str(tmp_path)) == []   # already there: nothing to do
+    finally:
+        stop.set()
+        os.environ.pop("MICROALIGNER_BIND_NUMA", None)
+        device.set_affinity(before)
+    assert os.sched_getaffinity(0) == before
