@@ -21,6 +21,9 @@
  * `fused` switches model the builds where OpenCV's v_muladd lowers to FMA).
  * They are pinned only by closed-form known-answer tests (tests/test_oracle_kat.py).
  * The NMI function IS pinned: tests check it against the installed scikit-learn.
+ * The pin for the rest is one run away on any machine with the reference's OpenCV:
+ * tests/golden/make_cv2_golden.py (numpy + cv2 only) writes tests/golden/cv2_4.5.5.npz,
+ * tests/test_cv2_golden.py holds every function below (and the HIP path) against it.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library.
