@@ -72,7 +72,9 @@ struct ma_ctx {
     // transfer engines (MA_ENGINE_H2D / MA_ENGINE_D2H): streams created on first use under `mu`
     hipStream_t engine[3] = {nullptr, nullptr, nullptr};
     std::mutex mu;
-    MaStageRing* stage[2] = {nullptr, nullptr};   // [0] host -> device, [1] device -> host; each used by one thread at a time
+    // staging rings per engine and direction ([engine][0] host -> device, [engine][1] device -> host): an engine is driven by
+    // one host thread at a time, so a ring is too
+    MaStageRing* stage[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     // MA_OPT_COMPANION_STREAM
     bool companion = true;
     // device int that the dog() chain sets when an input has max() == 0 but is not all zero (see d_dog_params_in);
