@@ -572,6 +572,10 @@ def test_stream_pairs_equals_the_one_pair_path_and_moves_every_byte_once(ctx):
     for r in parallel.stream_pairs(pairs[:4], params, warp=False, out=lambda i: (dst[i], None)):
         assert r.warped is None
     assert all(np.array_equal(dst[i], single[i][0]) for i in range(4))
+    # two compute lanes (pairs registered two at a time on two contexts): same bits, same order
+    two = list(parallel.stream_pairs(iter(pairs), params, warp=True, compute_lanes=2))
+    assert [r.index for r in two] == list(range(len(pairs)))
+    assert all(np.array_equal(r.flow, f) and np.array_equal(r.warped, w_) for r, (f, w_, _) in zip(two, single))
     # register_pairs routes host pairs through the stream; loaders are evaluated lazily; out= rows are filled in place
     flows = parallel.register_pairs(pairs[:4], params, warp=True)
     assert all(np.array_equal(f, single[i][0]) and np.array_equal(w_, single[i][1]) for i, (f, w_) in enumerate(flows))

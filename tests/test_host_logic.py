@@ -275,7 +275,7 @@ class _FakeStreamCtx:
             self.down += out.nbytes
 
 
-def test_stream_pairs_pipeline_logic_without_a_gpu():
+def test_stream_pairs_pipeline_logic_without_a_gpu(monkeypatch):
     """parallel.stream_pairs over a stand-in context: results in input order and equal to the stage applied pair by pair,
     lazily evaluated input, shape changes mid-stream, caller-provided outputs, byte counts, engine busy times, an
     exception in any engine or in the input generator surfaces in the consumer, and early exit of the consumer stops the
@@ -328,6 +328,26 @@ def test_stream_pairs_pipeline_logic_without_a_gpu():
         for res in parallel.stream_pairs(pairs[:4], stage=stage, out=lambda i: (dst_f[i], dst_w[i])):
             assert res.flow is not None and res.flow.base is dst_f
     assert np.array_equal(dst_f[2][..., 0], pairs[2][0] - pairs[2][1]) and np.array_equal(dst_w[3], pairs[3][1][::-1])
+
+    # two compute lanes (each pair registered by one of two threads with a context of its own): results still leave in
+    # input order although the lanes finish out of order
+    import time as _time
+    lanes_used = set()
+    monkeypatch.setattr(parallel, "_lane_context", lambda k: _FakeStreamCtx())
+
+    def uneven_stage(c, dref, dmov):
+        lanes_used.add(id(c))
+        _time.sleep(0.03 if int(dref.data[0, 0] * 1e6) % 2 else 0.0)      # some pairs take much longer than others
+        return stage(c, dref, dmov)
+
+    with use_context(fake):
+        st2 = {}
+        got2 = list(parallel.stream_pairs(iter(pairs), stage=uneven_stage, compute_lanes=2, stats=st2))
+    assert [r.index for r in got2] == list(range(len(pairs))) and len(lanes_used) == 2 and st2["compute_lanes"] == 2
+    for r, (ref, mov) in zip(got2, pairs):
+        assert np.array_equal(r.flow[..., 0], ref - mov) and np.array_equal(r.warped, mov[::-1])
+    assert {t.get("lane") for t in st2["timeline"]} == {0, 1}
+    assert not [t for t in threading.enumerate() if t.name.startswith("ma-engine-")]
 
     # errors: in the stage, in the input, in a bad output array
     def bad_stage(ctx, dref, dmov):

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--inputs", default="both")
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--timeline", action="store_true")
+    ap.add_argument("--trim", action="store_true", help="after --first-single: hand every pooled buffer back first")
+    ap.add_argument("--first-single", action="store_true", help="run the one-pair numpy path first (as bench.py does)")
+    ap.add_argument("--lanes", type=int, default=1, help="compute lanes of stream_pairs")
     ap.add_argument("--no-bind", action="store_true", help="leave the process on every CPU of the host")
     args = ap.parse_args()
     from microaligner_amd import parallel, synthetic
@@ -41,6 +44,24 @@ def main():
         params = dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True, tile_size=500, overlap=50)
     ref, mov = synthetic.make_pair(H, W, 1, dt)
     base = [(np.roll(ref, 53 * k, axis=0), np.roll(mov, 53 * k, axis=0)) for k in range(args.pairs)]
+    if args.first_single:
+        # what bench.py's host_inclusive leg does before its stream leg: the one-pair drop-in path on numpy arrays
+        from microaligner_amd import OptFlowRegistrator, Warper
+        for _ in range(3):
+            reg = OptFlowRegistrator()
+            reg.verbose = False
+            for k, v in params.items():
+                setattr(reg, k, v)
+            reg.ref_img, reg.mov_img = ref, mov
+            flow = reg.register()
+            w = Warper()
+            w.image, w.flow = mov, flow
+            w.warp()
+        del flow
+        if args.trim:
+            ctx.forget_host_arrays()
+            ctx.trim()
+        print("ran the one-pair path three times first" + (", then trimmed the context" if args.trim else ""), flush=True)
     variants = ["pageable", "pinned"] if args.inputs == "both" else [args.inputs]
     for v in variants:
         if v == "pinned":
@@ -52,17 +73,17 @@ def main():
                 pairs.append((pa, pb))
         else:
             pairs = base
-        for _ in parallel.stream_pairs(pairs[:3], params, depth=args.depth):
+        for _ in parallel.stream_pairs(pairs[:3], params, depth=args.depth, compute_lanes=args.lanes):
             pass
         stats, marks = {}, []
         t0 = time.perf_counter()
-        for res in parallel.stream_pairs(pairs, params, depth=args.depth, stats=stats):
+        for res in parallel.stream_pairs(pairs, params, depth=args.depth, stats=stats, compute_lanes=args.lanes):
             marks.append(time.perf_counter())
         wall = (marks[-1] - t0) * 1e3
         half = len(marks) // 2                     # the later half: the pipeline's backlog has drained by then
         steady = (marks[-1] - marks[half - 1]) / (len(marks) - half) * 1e3
         n = len(pairs)
-        print(f"[{v:8s}] {args.dtype} {H}x{W}: steady {steady:7.2f} ms/pair, wall {wall / n:7.2f} ms/pair | busy per pair: "
+        print(f"[{v:8s}] lanes {args.lanes} {args.dtype} {H}x{W}: steady {steady:7.2f} ms/pair, wall {wall / n:7.2f} ms/pair | busy per pair: "
               f"h2d {stats['h2d_busy_ms'] / n:6.1f} ms ({stats['h2d_bytes'] / stats['h2d_busy_ms'] / 1e6:5.1f} GB/s)  "
               f"compute {stats['compute_busy_ms'] / n:6.1f} ms  d2h {stats['d2h_busy_ms'] / n:6.1f} ms "
               f"({stats['d2h_bytes'] / stats['d2h_busy_ms'] / 1e6:5.1f} GB/s)", flush=True)
