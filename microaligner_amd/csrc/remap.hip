@@ -7,7 +7,11 @@
 #include "ma_internal.h"
 
 #include <climits>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 
 namespace {
 
@@ -548,44 +552,108 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
     for (int i = 0; i < n_pages; i++) MA_REQUIRE(pages_host[i] && out_host[i], "NULL page pointer");
     if (n_pages == 0) return MA_OK;
     MA_HIP(hipSetDevice(ctx->device));
+    // Three engines of the ctx (include/microaligner_hip.h, "transfer engines"): an upload thread copies page i into input
+    // slot i % NS on the H2D stream, this thread launches the warp on the ctx stream, a download thread copies the result
+    // out on the D2H stream; events order the streams, counters under one mutex order the threads.  Pageable pages (numpy
+    // arrays, rows of a memmapped TIFF) are staged by the engines through page-locked chunks -- the runtime's own staging
+    // of pageable memory reached 14 GB/s per direction here, the engines 2 - 3 x that (profiles/r04_notes.md).
     constexpr int NS = 3;
     const int ns = n_pages < NS ? n_pages : NS;
-    const size_t bytes = ma_align_up((size_t)H * W * ma_esize(dtype), 256);
-    MA_TRY(ma_ws_reserve(ctx, bytes * 2 * ns));  // device buffers come from the context workspace
-    struct Slot { hipStream_t st = nullptr; void *din = nullptr, *dout = nullptr; };
-    Slot slots[NS];
-    hipEvent_t flow_ready = nullptr;
-    auto cleanup = [&]() {
-        for (auto& s : slots)
-            if (s.st) { (void)hipStreamSynchronize(s.st); (void)hipStreamDestroy(s.st); }
-        if (flow_ready) (void)hipEventDestroy(flow_ready);
-    };
-#define PG_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ma_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); cleanup(); return MA_EHIP; } } while (0)
-    PG_HIP(hipEventCreateWithFlags(&flow_ready, hipEventDisableTiming));
-    PG_HIP(hipEventRecord(flow_ready, ctx->stream));  // the flow may still be in flight on the ctx stream
-    for (int k = 0; k < ns; k++) {
-        PG_HIP(hipStreamCreateWithFlags(&slots[k].st, hipStreamNonBlocking));
-        slots[k].din = (char*)ctx->ws + bytes * (2 * k);
-        slots[k].dout = (char*)ctx->ws + bytes * (2 * k + 1);
-        PG_HIP(hipStreamWaitEvent(slots[k].st, flow_ready, 0));
-    }
-    const float2* f = (const float2*)flow;
     const size_t nb = (size_t)H * W * ma_esize(dtype);
+    const size_t bytes = ma_align_up(nb, 256);
+    MA_TRY(ma_ws_reserve(ctx, bytes * 2 * ns));  // device buffers come from the context workspace
+    void *din[NS], *dout[NS];
+    hipEvent_t ev_up[NS] = {nullptr, nullptr, nullptr}, ev_k[NS] = {nullptr, nullptr, nullptr};
+    auto cleanup = [&]() {
+        for (int k = 0; k < NS; k++) {
+            if (ev_up[k]) (void)hipEventDestroy(ev_up[k]);
+            if (ev_k[k]) (void)hipEventDestroy(ev_k[k]);
+        }
+    };
+    for (int k = 0; k < ns; k++) {
+        din[k] = (char*)ctx->ws + bytes * (2 * k);
+        dout[k] = (char*)ctx->ws + bytes * (2 * k + 1);
+        if (hipEventCreateWithFlags(&ev_up[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_k[k], hipEventDisableTiming) != hipSuccess) {
+            cleanup();
+            ma_set_error("hipEventCreate failed");
+            return MA_EHIP;
+        }
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    int uploaded = 0, launched = 0, downloaded = 0, failed = MA_OK;
+    std::string what;
+    auto fail = [&](int rc) {   // called with mu held
+        if (failed == MA_OK) { failed = rc; what = ma_last_error(); }
+        cv.notify_all();
+    };
+    std::thread up([&]() {
+        for (int i = 0; i < n_pages; i++) {
+            const int k = i % ns;
+            {   // slot k is free again once page i - ns has been downloaded
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return failed != MA_OK || downloaded > i - ns; });
+                if (failed != MA_OK) return;
+            }
+            int rc = ma_engine_memcpy_h2d(ctx, MA_ENGINE_H2D, din[k], pages_host[i], nb);
+            if (rc == MA_OK) rc = ma_engine_record(ctx, MA_ENGINE_H2D, ev_up[k]);
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc != MA_OK) { fail(rc); return; }
+            uploaded = i + 1;
+            cv.notify_all();
+        }
+    });
+    std::thread down([&]() {
+        for (int i = 0; i < n_pages; i++) {
+            const int k = i % ns;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return failed != MA_OK || launched > i; });
+                if (failed != MA_OK) return;
+            }
+            int rc = ma_engine_wait(ctx, MA_ENGINE_D2H, ev_k[k]);
+            if (rc == MA_OK) rc = ma_engine_memcpy_d2h(ctx, MA_ENGINE_D2H, out_host[i], dout[k], nb);
+            std::lock_guard<std::mutex> lk(mu);
+            if (rc != MA_OK) { fail(rc); return; }
+            downloaded = i + 1;
+            cv.notify_all();
+        }
+    });
+    const float2* f = (const float2*)flow;
     dim3 grid((W + 255) / 256, (H + WARP_ROWS - 1) / WARP_ROWS), block(256);
     for (int i = 0; i < n_pages; i++) {
-        Slot& s = slots[i % ns];  // stream order keeps the slot's buffers safe: copy-in waits for the previous copy-out
-        ctx->h2d_bytes += nb;
-        ctx->d2h_bytes += nb;
-        PG_HIP(hipMemcpyAsync(s.din, pages_host[i], nb, hipMemcpyHostToDevice, s.st));
-        if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t, false>), grid, block, 0, s.st, (const uint8_t*)s.din, g, f, (uint8_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0, 0);
-        else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t, false>), grid, block, 0, s.st, (const uint16_t*)s.din, g, f, (uint16_t*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0, 0);
-        else hipLaunchKernelGGL((warp_tiled_kernel<float, false>), grid, block, 0, s.st, (const float*)s.din, g, f, (float*)s.dout, (float*)nullptr, (unsigned*)nullptr, 0, 0);
-        PG_HIP(hipGetLastError());
-        PG_HIP(hipMemcpyAsync(out_host[i], s.dout, nb, hipMemcpyDeviceToHost, s.st));
+        const int k = i % ns;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return failed != MA_OK || uploaded > i; });
+            if (failed != MA_OK) break;
+        }
+        hipError_t e = hipStreamWaitEvent(ctx->stream, ev_up[k], 0);
+        if (e == hipSuccess) {
+            if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t, false>), grid, block, 0, ctx->stream, (const uint8_t*)din[k], g, f, (uint8_t*)dout[k], (float*)nullptr, (unsigned*)nullptr, 0, 0);
+            else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t, false>), grid, block, 0, ctx->stream, (const uint16_t*)din[k], g, f, (uint16_t*)dout[k], (float*)nullptr, (unsigned*)nullptr, 0, 0);
+            else hipLaunchKernelGGL((warp_tiled_kernel<float, false>), grid, block, 0, ctx->stream, (const float*)din[k], g, f, (float*)dout[k], (float*)nullptr, (unsigned*)nullptr, 0, 0);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(ev_k[k], ctx->stream);
+        std::lock_guard<std::mutex> lk(mu);
+        if (e != hipSuccess) {
+            ma_set_error("warp of page %d failed: %s", i, hipGetErrorString(e));
+            fail(MA_EHIP);
+            break;
+        }
+        launched = i + 1;
+        cv.notify_all();
     }
-    for (int k = 0; k < ns; k++) PG_HIP(hipStreamSynchronize(slots[k].st));
-#undef PG_HIP
+    up.join();
+    down.join();
+    (void)hipStreamSynchronize(ctx->stream);
     cleanup();
+    if (failed != MA_OK) {
+        ma_set_error("%s", what.c_str());
+        return failed;
+    }
     return MA_OK;
 }
 
