@@ -343,8 +343,11 @@ def host_stream_leg(n_pairs, ref, mov, params, dtype):
         marks.append(time.perf_counter())
         checks.append((float(res.flow[::997, ::991].sum()), int(res.warped[::997, ::991].astype(np.int64).sum())))
     wall = (marks[-1] - t0) / n_pairs               # includes filling and draining the pipeline once
-    half = n_pairs // 2                             # sustained: arrival interval over the later half of the stream
-    dt = (marks[-1] - marks[half - 1]) / (n_pairs - half)
+    # sustained: the arrival interval over the later half of the stream.  With L compute lanes results arrive in groups of L,
+    # so intervals are taken L results apart; the median keeps one hiccup of the host out of the figure
+    half, L_ = n_pairs // 2, max(1, int(stats.get("compute_lanes", 1)))
+    spans = sorted((marks[i] - marks[i - L_]) / L_ for i in range(max(half, L_), n_pairs))
+    dt = spans[len(spans) // 2] if len(spans) % 2 else 0.5 * (spans[len(spans) // 2 - 1] + spans[len(spans) // 2])
     in_bytes = sum(a.nbytes + b.nbytes for a, b in pairs)
     H, W = ref.shape
     out_bytes = n_pairs * (H * W * 8 + H * W * np.dtype(dtype).itemsize)

@@ -80,8 +80,9 @@ def main():
         for res in parallel.stream_pairs(pairs, params, depth=args.depth, stats=stats, compute_lanes=args.lanes):
             marks.append(time.perf_counter())
         wall = (marks[-1] - t0) * 1e3
-        half = len(marks) // 2                     # the later half: the pipeline's backlog has drained by then
-        steady = (marks[-1] - marks[half - 1]) / (len(marks) - half) * 1e3
+        half, L_ = len(marks) // 2, max(1, stats["compute_lanes"])     # the later half, intervals one lane group apart, median
+        spans = sorted((marks[i] - marks[i - L_]) / L_ for i in range(max(half, L_), len(marks)))
+        steady = (spans[len(spans) // 2] if len(spans) % 2 else 0.5 * (spans[len(spans) // 2 - 1] + spans[len(spans) // 2])) * 1e3
         n = len(pairs)
         print(f"[{v:8s}] lanes {args.lanes} {args.dtype} {H}x{W}: steady {steady:7.2f} ms/pair, wall {wall / n:7.2f} ms/pair | busy per pair: "
               f"h2d {stats['h2d_busy_ms'] / n:6.1f} ms ({stats['h2d_bytes'] / stats['h2d_busy_ms'] / 1e6:5.1f} GB/s)  "
