@@ -584,30 +584,27 @@ def _gather(local: dict, n_units: int, gather: bool, dst: int = 0):
     return [merged[i] for i in range(n_units)]
 
 
-def warp_pages(pages: Sequence, flow, tile_size: int = 1000, overlap: int = 100, gather: bool = True):
+def warp_pages(pages: Sequence, flow, tile_size: int = 1000, overlap: int = 100, gather: bool = True, out=None):
     """Apply ONE flow to many pages (channels x z-planes of a cycle, __main__.py:288-302,427-433).  Pages are dealt
-    round-robin to the ranks; each rank uploads the flow once and streams its share through the overlapped
-    page-warp driver (ma_warp_pages_host).  Returns the warped pages in page order on rank 0 (gather=True) or
-    {page_index: array} for the local share."""
+    round-robin to the ranks (a page may be a loader: a zero-argument callable evaluated by its owner only); each rank
+    uploads the flow once and streams its share through the page-warp driver (ma_warp_pages_host: upload, warp and download
+    of consecutive pages on the three engines of its context).
+    out: an array (n_pages, H, W) every rank can write -- shared_array() or the np.memmap of the output file, the way the
+    reference writes every page into its memmapped TIFF (__main__.py:116-132) -- whose rows the download engine fills in
+    place; nothing is gathered then and every rank returns `out`.  Otherwise: the warped pages in page order on rank 0
+    (gather=True, pickled over gloo: for small jobs) or {page_index: array} for the local share."""
     from .device import get_context
     rank, ws = world()
     mine = shard(len(pages), rank, ws)
     ctx = get_context()
-    outs = ctx.warp_pages([pages[i] for i in mine], ctx.asdevice(flow), tile_size, overlap) if mine else []
-    local = dict(zip(mine, outs))
-    if not gather:
-        return local
-    if ws == 1:
-        return [local[i] for i in range(len(pages))]
-    import torch.distributed as dist
-    bucket = [None] * ws if rank == 0 else None
-    dist.gather_object(local, bucket, dst=0)
-    if rank != 0:
-        return None
-    merged = {}
-    for part in bucket:
-        merged.update(part)
-    return [merged[i] for i in range(len(pages))]
+    rows = [out[i] for i in mine] if out is not None else None
+    outs = ctx.warp_pages([_unit(pages, i) for i in mine], ctx.asdevice(flow), tile_size, overlap, rows) if mine else []
+    if out is not None:
+        if hasattr(out, "flush"):
+            out.flush()
+        _barrier()
+        return out
+    return _gather(dict(zip(mine, outs)), len(pages), gather)
 
 
 def register_cycle_chain(cycles: Sequence, ref_channel_ids=None, params: Optional[dict] = None):

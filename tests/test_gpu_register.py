@@ -438,6 +438,26 @@ def test_page_warp_driver_matches_single_page_warps(ctx):
         w.warp_pages([pages[0][:10]])
 
 
+def test_sharded_page_warps_fill_the_callers_rows(ctx, tmp_path):
+    """parallel.warp_pages: pages dealt to the ranks (one rank here), loaders evaluated by their owner, results written in
+    place into the rows of an array every rank can map (a .npy memory map: the output file of the pipeline)."""
+    from microaligner_amd import parallel
+    H, W = 410, 530
+    rng = np.random.default_rng(11)
+    pages = [rng.integers(0, 65535, (H, W)).astype(np.uint16) for _ in range(5)]
+    from scipy.ndimage import gaussian_filter
+    flow = np.stack([gaussian_filter(rng.standard_normal((H, W)), 5) * 30 for _ in range(2)], -1).astype(np.float32)
+    exp = [RO.warp(p, flow, 150, 20) for p in pages]
+    got = parallel.warp_pages(pages, flow, 150, 20)
+    assert all(np.array_equal(g, e) for g, e in zip(got, exp))
+    called = []
+    store = np.lib.format.open_memmap(tmp_path / "pages.npy", mode="w+", dtype=np.uint16, shape=(5, H, W))
+    res = parallel.warp_pages([(lambda k=k: (called.append(k), pages[k])[1]) for k in range(5)], flow, 150, 20, out=store)
+    assert res is store and called == [0, 1, 2, 3, 4]
+    del res, store
+    assert np.array_equal(np.load(tmp_path / "pages.npy"), np.stack(exp))
+
+
 def test_reference_shaped_numpy_loop_uploads_nothing_twice(ctx):
     """The reference's own statements, numpy in and numpy out (microaligner/__main__.py:418-433 and the per-page loop
     of warp_and_save_pages :296-301): register(), then Warper.warp() of the moving image, then the same flow set on the
