@@ -592,6 +592,17 @@ def test_stream_pairs_equals_the_one_pair_path_and_moves_every_byte_once(ctx):
     for r in parallel.stream_pairs(pairs[:4], params, warp=False, out=lambda i: (dst[i], None)):
         assert r.warped is None
     assert all(np.array_equal(dst[i], single[i][0]) for i in range(4))
+    # lanes by default: two when two working sets fit the device comfortably, one when they would not
+    assert stats["compute_lanes"] == 2
+    import microaligner_amd.device as D
+    real_info = D.device_info
+    D.device_info = lambda dev=0: dict(real_info(dev), mem_total=1 << 28)     # a device with 256 MiB
+    try:
+        st1 = {}
+        small = list(parallel.stream_pairs(iter(pairs[:3]), params, warp=True, stats=st1))
+    finally:
+        D.device_info = real_info
+    assert st1["compute_lanes"] == 1 and all(np.array_equal(r.flow, single[i][0]) for i, r in enumerate(small))
     # two compute lanes (pairs registered two at a time on two contexts): same bits, same order
     two = list(parallel.stream_pairs(iter(pairs), params, warp=True, compute_lanes=2))
     assert [r.index for r in two] == list(range(len(pairs)))
