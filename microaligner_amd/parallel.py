@@ -226,8 +226,9 @@ def stream_pairs(pairs, params: Optional[dict] = None, warp: bool = True, depth:
     pair k+1 and the download of pair k-1 hidden behind the kernels of pair k.
 
     The reference meets its inputs one page at a time (TIFF pages read in __main__.py:398-433, "one page in memory",
-    README.md:5) and overlaps work through dask (flow_calc.py:88-98, utils.py:117-123).  Here ONE context drives three
-    engines (include/microaligner_hip.h, "transfer engines"), each from its own persistent host thread:
+    README.md:5) and overlaps work through dask (flow_calc.py:88-98, utils.py:117-123).  Here one context drives three
+    engines (include/microaligner_hip.h, "transfer engines"), each from its own persistent host thread (the compute engine
+    may have more than one lane, see compute_lanes):
 
       upload   : pulls the next pair from `pairs` (any iterable, evaluated lazily and on this thread: a generator that
                  reads files overlaps too), copies it into a free device input slot on the H2D stream, records an event;
@@ -239,15 +240,16 @@ def stream_pairs(pairs, params: Optional[dict] = None, warp: bool = True, depth:
     Events order the engines on the device; the host threads never wait for each other's copies.  Every byte crosses the
     bus once (ma_ctx_transfer_stats).  Results come out in input order as PairResult(index, flow, warped, reports);
     `for flow, warped in stream_pairs(...)` works too.  `depth`: pairs that may wait between two engines (device memory:
-    depth + 1 input slots, result buffers of up to depth + 1 pairs).  `stats`, if given, receives the busy time of each
+    depth + compute_lanes input slots, result buffers of as many pairs).  `stats`, if given, receives the busy time of each
     engine, the wall time and the byte counts when the stream ends.  `out`: optional callable index -> (flow_out,
     warped_out) host arrays to fill instead of pool arrays (e.g. rows of a memmap; either may be None).
     `stage`: replaces the compute step (align_pairs uses it): callable (ctx, dref, dmov) -> ([device arrays to
     download], reports, extra).  Bit-identical to the one-pair path: same kernels on the same inputs.
     `compute_lanes`: pairs registered at the same time, each by a compute thread with a context of its own (own stream,
     workspace and buffer cache: ~50 GB of HBM per lane at 16384^2); the coarse levels of one pair, whose few windows leave
-    most of the chip idle, then run under the full-resolution level of another: 72 instead of 79 ms per 16384^2 pair with
-    two lanes (three: 70, the download engine becomes the bound).  Default (None): two lanes when two such working sets
+    most of the chip idle, then run under the full-resolution level of another: 74.6 instead of 79.0 ms per 16384^2 pair
+    with two lanes, 0.48 instead of 1.1 ms per 512^2 pair (three lanes: ~73 ms, the download engine comes into play;
+    profiles/r04_notes.md).  Default (None): two lanes when two such working sets
     fit comfortably into the device's memory (judged from the first pair: 200 bytes per pixel and lane against 60 % of the
     HBM), else one.  Uploads, downloads and the order of the results are the same for any number of lanes."""
     import queue
