@@ -82,8 +82,10 @@ int ma_ctx_transfer_stats(ma_ctx* ctx, unsigned long long* h2d_bytes, unsigned l
 /* Run-time switches of a ctx.  MA_OPT_COMPANION_STREAM (default 1): ma_optflow_register computes the dog() of the
  * reference and of the moving image of every level on a second, low-priority HIP stream under the level loop; 0 keeps
  * everything on the ctx stream (same kernels, same inputs, same results -- for alone-on-the-chip kernel timings that are
- * comparable from run to run).  MA_OPT_WORKSPACE_LIMIT: same as ma_ctx_set_workspace_limit. */
-enum ma_option { MA_OPT_COMPANION_STREAM = 1, MA_OPT_WORKSPACE_LIMIT = 2 };
+ * comparable from run to run).  MA_OPT_WORKSPACE_LIMIT: same as ma_ctx_set_workspace_limit.
+ * MA_OPT_WARP_BAND_BYTES (default 32 MiB): ma_warp_pages_host moves a page in bands of whole tile rows of at least this
+ * many bytes (1: one tile row per band -- for tests of the band logic on small pages). */
+enum ma_option { MA_OPT_COMPANION_STREAM = 1, MA_OPT_WORKSPACE_LIMIT = 2, MA_OPT_WARP_BAND_BYTES = 3 };
 int ma_ctx_set_option(ma_ctx* ctx, int option, long long value);
 int ma_ctx_get_option(ma_ctx* ctx, int option, long long* value);
 
@@ -108,9 +110,13 @@ int ma_engine_sync(ma_ctx* ctx, int engine);
  * page-locked 32 MiB chunks per direction, filled / drained by a small pool of host threads
  * (MICROALIGNER_COPY_THREADS, default 8 on hosts with >= 32 hardware threads) while the DMA engine moves the previous
  * chunk, so that the device only ever sees page-locked copies (the runtime's own staging of pageable memory shares
- * the shader engines with running kernels).  ma_host_parallel_copy is that pool's memcpy, exported so that it can be
- * checked without a GPU.  Host-only. */
+ * the shader engines with running kernels).  Each direction has its own pool; the drain of a download writes the
+ * caller's array with non-temporal stores (the lines are not fetched for ownership nor kept in cache:
+ * MICROALIGNER_COPY_NT, bit 0 = fills, bit 1 = drains, default 2).  ma_host_parallel_copy is the upload pool's memcpy,
+ * ma_host_stream_copy the download pool's streaming copy, exported so that they can be checked without a GPU.
+ * Host-only. */
 int ma_host_parallel_copy(void* dst, const void* src, size_t bytes);
+int ma_host_stream_copy(void* dst, const void* src, size_t bytes);
 /* Host wait for an event (any engine). */
 int ma_event_sync(ma_ctx* ctx, void* ev);
 

@@ -16,7 +16,7 @@ MA_FB_MULADD_FUSED = 1
 MA_KNN_AUTO, MA_KNN_EXACT, MA_KNN_FILTERED = 0, 1, 2   # enum ma_knn_mode
 MA_DOG_FUSED_BLUR, MA_DOG_FUSED_SCALE = 1, 2
 MA_FLOW_CELL_REPLICAS = 8
-MA_OPT_COMPANION_STREAM, MA_OPT_WORKSPACE_LIMIT = 1, 2      # enum ma_option
+MA_OPT_COMPANION_STREAM, MA_OPT_WORKSPACE_LIMIT, MA_OPT_WARP_BAND_BYTES = 1, 2, 3      # enum ma_option
 MA_ENGINE_COMPUTE, MA_ENGINE_H2D, MA_ENGINE_D2H = 0, 1, 2   # enum ma_engine
 
 KERNEL_IDS = {"polyexp_m0": 0, "blur_v": 1, "blur_h_solve": 2, "warp": 3, "merge": 4, "pyr_down": 5,
@@ -111,6 +111,7 @@ SIGNATURES.update({
     "ma_engine_sync": (_i, [_vp, _i]),
     "ma_event_sync": (_i, [_vp, _vp]),
     "ma_host_parallel_copy": (_i, [_vp, _vp, _sz]),
+    "ma_host_stream_copy": (_i, [_vp, _vp, _sz]),
     "ma_convert_f32": (_i, [_vp, _vp, _i, _sz, _vp]),
 })
 

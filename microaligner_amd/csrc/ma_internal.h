@@ -11,6 +11,7 @@
 #include <string>
 #include <unordered_map>
 #include <utility>
+#include <functional>
 #include <vector>
 
 #include "../../include/microaligner_hip.h"
@@ -77,6 +78,8 @@ struct ma_ctx {
     MaStageRing* stage[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
     // MA_OPT_COMPANION_STREAM
     bool companion = true;
+    // MA_OPT_WARP_BAND_BYTES
+    size_t warp_band_bytes = (size_t)32 << 20;
     // device int that the dog() chain sets when an input has max() == 0 but is not all zero (see d_dog_params_in);
     // NULL outside ma_optflow_register
     int* dog_sticky = nullptr;
@@ -91,6 +94,22 @@ ma_ctx* ma_ctx_side(ma_ctx* ctx);
 void ma_stage_rings_destroy(ma_ctx* ctx);
 // stream of an engine (MA_ENGINE_*); nullptr + error set on failure
 hipStream_t ma_engine_stream(ma_ctx* ctx, int engine);
+// One host <-> device copy on a transfer engine whose caller wants to act between its pieces (the bands of the page-warp
+// driver) without giving up the overlap of staging copy and DMA at every piece, as a sequence of ma_engine_memcpy_* calls
+// would.  cuts[0 .. ncuts): ascending end offsets of the pieces, cuts[ncuts - 1] == bytes.
+//   h2d: enqueued(j) is called, in order, as soon as every byte of piece j has been handed to the engine's stream (an event
+//        recorded in the callback fires when piece j is in HBM);
+//   d2h: before(j) is called, in order, before the first byte of piece j is read (the callback makes the engine's stream wait
+//        for whatever produces the piece).
+// Both return when the whole copy is complete; a callback's non-zero code stops the copy and is returned.  h2d with
+// wait == false returns as soon as the last byte has been handed to the stream (a pageable source has been read completely
+// by then, a page-locked one must stay untouched until the stream has been waited for): a sequence of pages keeps the engine
+// busy across the page boundaries, the caller ends it with ma_engine_sync.
+typedef std::function<int(int)> MaPieceFn;
+int ma_engine_h2d_pieces(ma_ctx* ctx, int engine, void* dst, const void* src_host, size_t bytes, const size_t* cuts, int ncuts,
+                         const MaPieceFn& enqueued, bool wait = true);
+int ma_engine_d2h_pieces(ma_ctx* ctx, int engine, void* dst_host, const void* src, size_t bytes, const size_t* cuts, int ncuts,
+                         const MaPieceFn& before);
 // event i of the ctx's pool of timing-free events for ordering its two streams (created on demand; nullptr on failure)
 hipEvent_t ma_ctx_sync_event(ma_ctx* ctx, size_t i);
 

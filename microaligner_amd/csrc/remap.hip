@@ -6,12 +6,17 @@
 // HBM-bound gathers, rows coalesced along x; the tiled kernels give a thread 8 rows and issue all their loads first.
 #include "ma_internal.h"
 
+#include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
 
 namespace {
 
@@ -264,6 +269,31 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
         }
     }
     if (MM) d_block_minmax(lo, hi, part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+}
+
+// the rows [y_begin, y_end) of warp_tiled_kernel's result (bands of the page-warp driver, ma_warp_pages_host)
+template <typename T>
+__global__ __launch_bounds__(256) void warp_band_kernel(const T* __restrict__ img, MaTiling g,
+                                                        const float2* __restrict__ flow, T* __restrict__ out,
+                                                        int y_begin, int y_end)
+{
+    constexpr int WR = WARP_ROWS;
+    const int x = blockIdx.x * 256 + threadIdx.x, y0 = y_begin + blockIdx.y * WR;
+    if (x >= g.W) return;
+    const int ox = g.T > 0 ? (x / g.T) * g.T - g.ov : 0;
+    float2 f[WR];
+#pragma unroll
+    for (int r = 0; r < WR; r++) f[r] = flow[(size_t)min(y0 + r, y_end - 1) * g.W + x];
+    T res[WR];
+#pragma unroll
+    for (int r = 0; r < WR; r++) {
+        const int y = min(y0 + r, y_end - 1);
+        const int oy = g.T > 0 ? (y / g.T) * g.T - g.ov : 0;
+        res[r] = warp_tiled_px<T>(img, g, f[r], x, y, oy, ox);
+    }
+#pragma unroll
+    for (int r = 0; r < WR; r++)
+        if (y0 + r < y_end) out[(size_t)(y0 + r) * g.W + x] = res[r];
 }
 
 // ---- flow merge ---------------------------------------------------------------------------------
@@ -535,11 +565,13 @@ int ma_warp_tiled_flowcells(ma_ctx* ctx, const void* img, int dtype, int H, int 
 
 // ---- page-warp driver ---------------------------------------------------------------------
 // warp_and_save_pages (microaligner/__main__.py:288-302): every channel / z page of a cycle is warped with the
-// SAME flow.  The flow stays in HBM; pages stream through NS slots, each with its own HIP stream and device
-// buffer pair, so the H2D copy of page i+1, the kernel of page i and the D2H copy of page i-1 overlap.  Copies go
-// straight between the caller's buffers and HBM: on this platform resident pageable memory moves at the pinned
-// rate (56 GB/s, tools/ubench_pcie.hip), a pinned staging copy only adds a 28 GB/s memcpy and hipHostMalloc
-// costs 100 ms per 512 MiB.
+// SAME flow.  The flow stays in HBM; pages stream through NS slots (a device buffer pair each) on the three engines
+// of the context, so the upload of one piece, the kernel of the previous one and the download of the one before
+// overlap.  The unit of the pipeline is a BAND of whole tile rows, not a page: an output pixel only reads source
+// pixels of its own window (warper.py:29-76 cuts the windows before cv2.remap sees them), so the rows of tile row
+// ty are complete once source rows < (ty + 1) * tile + overlap have arrived -- a single page (Warper.warp() of a
+// host image, the reference's own per-page loop) overlaps its own upload, kernel and download, and the first and
+// last page of a longer run lose only a band to filling and draining.
 int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* out_host, int n_pages, int dtype,
                        int H, int W, const float* flow, int tile, int overlap)
 {
@@ -552,42 +584,70 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
     for (int i = 0; i < n_pages; i++) MA_REQUIRE(pages_host[i] && out_host[i], "NULL page pointer");
     if (n_pages == 0) return MA_OK;
     MA_HIP(hipSetDevice(ctx->device));
-    // Three engines of the ctx (include/microaligner_hip.h, "transfer engines"): an upload thread copies page i into input
-    // slot i % NS on the H2D stream, this thread launches the warp on the ctx stream, a download thread copies the result
-    // out on the D2H stream; events order the streams, counters under one mutex order the threads.  Pageable pages (numpy
-    // arrays, rows of a memmapped TIFF) are staged by the engines through page-locked chunks -- the runtime's own staging
-    // of pageable memory reached 14 GB/s per direction here, the engines 2 - 3 x that (profiles/r04_notes.md).
+    // An upload thread copies band after band into input slot page % NS on the H2D stream, this thread launches the
+    // band's warp on the ctx stream, a download thread copies its rows out on the D2H stream; events order the streams,
+    // counters under one mutex order the threads.  Pageable pages (numpy arrays, rows of a memmapped TIFF) are staged
+    // by the engines through page-locked chunks -- the runtime's own staging of pageable memory reached 14 GB/s per
+    // direction here, the engines 2 - 3 x that (profiles/r04_notes.md).
     constexpr int NS = 3;
     const int ns = n_pages < NS ? n_pages : NS;
-    const size_t nb = (size_t)H * W * ma_esize(dtype);
+    const size_t esz = ma_esize(dtype), rowb = (size_t)W * esz;
+    const size_t nb = (size_t)H * rowb;
     const size_t bytes = ma_align_up(nb, 256);
+    // bands: whole tile rows, at least MA_OPT_WARP_BAND_BYTES each (32 MiB: a transfer below that no longer runs at the
+    // link rate); an untiled warp (tile == 0: one window) is one band
+    const size_t MIN_BAND = ctx->warp_band_bytes;
+    int band_rows = H;
+    if (g.T > 0) {
+        const size_t tr = (MIN_BAND + (size_t)g.T * rowb - 1) / ((size_t)g.T * rowb);   // tile rows per band
+        band_rows = (int)std::min<size_t>((size_t)H, tr * (size_t)g.T);
+    }
+    const int nband = (H + band_rows - 1) / band_rows;
+    const long long n_units = (long long)n_pages * nband;
     MA_TRY(ma_ws_reserve(ctx, bytes * 2 * ns));  // device buffers come from the context workspace
     void *din[NS], *dout[NS];
-    hipEvent_t ev_up[NS] = {nullptr, nullptr, nullptr}, ev_k[NS] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_up((size_t)ns * nband, nullptr), ev_k((size_t)ns * nband, nullptr);
     auto cleanup = [&]() {
-        for (int k = 0; k < NS; k++) {
-            if (ev_up[k]) (void)hipEventDestroy(ev_up[k]);
-            if (ev_k[k]) (void)hipEventDestroy(ev_k[k]);
-        }
+        for (hipEvent_t e : ev_up) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ev_k) if (e) (void)hipEventDestroy(e);
     };
     for (int k = 0; k < ns; k++) {
         din[k] = (char*)ctx->ws + bytes * (2 * k);
         dout[k] = (char*)ctx->ws + bytes * (2 * k + 1);
-        if (hipEventCreateWithFlags(&ev_up[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_k[k], hipEventDisableTiming) != hipSuccess) {
+    }
+    for (size_t e = 0; e < ev_up.size(); e++)
+        if (hipEventCreateWithFlags(&ev_up[e], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_k[e], hipEventDisableTiming) != hipSuccess) {
             cleanup();
             ma_set_error("hipEventCreate failed");
             return MA_EHIP;
         }
+    // output rows of band b, and the source rows that must be resident before it runs
+    auto band_begin = [&](int b) { return b * band_rows; };
+    auto band_end = [&](int b) { return std::min(H, (b + 1) * band_rows); };
+    auto src_end = [&](int b) { return b == nband - 1 ? H : std::min(H, (b + 1) * band_rows + g.ov); };
+    // byte offsets at which the bands end: in the source (a band's window reaches `overlap` rows further) and in the result
+    std::vector<size_t> cuts_src(nband), cuts_out(nband);
+    for (int b = 0; b < nband; b++) {
+        cuts_src[b] = (size_t)src_end(b) * rowb;
+        cuts_out[b] = (size_t)band_end(b) * rowb;
     }
+    const bool TRACE = getenv("MICROALIGNER_TRACE_PAGES") != nullptr;   // timeline of the three threads on stderr
+    const auto T0 = std::chrono::steady_clock::now();
+    auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - T0).count(); };
+    if (TRACE) fprintf(stderr, "[pages] %d pages, %d bands of %d rows\n", n_pages, nband, band_rows);
     std::mutex mu;
     std::condition_variable cv;
-    int uploaded = 0, launched = 0, downloaded = 0, failed = MA_OK;
+    long long uploaded = 0, launched = 0;   // in units (page * nband + band)
+    int downloaded = 0;                     // in pages
+    int failed = MA_OK;
     std::string what;
     auto fail = [&](int rc) {   // called with mu held
         if (failed == MA_OK) { failed = rc; what = ma_last_error(); }
         cv.notify_all();
     };
+    // A page is ONE copy per direction (ma_engine_*_pieces): the staging of pageable memory keeps its chunks in flight
+    // across the band boundaries, the bands only decide when the events are recorded and waited for.
     std::thread up([&]() {
         for (int i = 0; i < n_pages; i++) {
             const int k = i % ns;
@@ -596,60 +656,82 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
                 cv.wait(lk, [&] { return failed != MA_OK || downloaded > i - ns; });
                 if (failed != MA_OK) return;
             }
-            int rc = ma_engine_memcpy_h2d(ctx, MA_ENGINE_H2D, din[k], pages_host[i], nb);
-            if (rc == MA_OK) rc = ma_engine_record(ctx, MA_ENGINE_H2D, ev_up[k]);
+            const int rc = ma_engine_h2d_pieces(ctx, MA_ENGINE_H2D, din[k], pages_host[i], nb, cuts_src.data(), nband, [&](int b) {
+                const int r = ma_engine_record(ctx, MA_ENGINE_H2D, ev_up[(size_t)k * nband + b]);
+                if (TRACE) fprintf(stderr, "[pages] %8.2f up   p%d b%d\n", now_ms(), i, b);
+                std::lock_guard<std::mutex> lk(mu);
+                if (r != MA_OK) return r;
+                if (failed != MA_OK) return failed;
+                uploaded = (long long)i * nband + b + 1;
+                cv.notify_all();
+                return (int)MA_OK;
+            }, false);   // no wait at the page boundary: the next page's first chunk is staged under this page's last DMAs
+            if (rc != MA_OK) {
+                std::lock_guard<std::mutex> lk(mu);
+                fail(rc);
+                return;
+            }
+        }
+        const int rc = ma_engine_sync(ctx, MA_ENGINE_H2D);
+        if (rc != MA_OK) {
             std::lock_guard<std::mutex> lk(mu);
-            if (rc != MA_OK) { fail(rc); return; }
-            uploaded = i + 1;
-            cv.notify_all();
+            fail(rc);
         }
     });
     std::thread down([&]() {
         for (int i = 0; i < n_pages; i++) {
             const int k = i % ns;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return failed != MA_OK || launched > i; });
-                if (failed != MA_OK) return;
-            }
-            int rc = ma_engine_wait(ctx, MA_ENGINE_D2H, ev_k[k]);
-            if (rc == MA_OK) rc = ma_engine_memcpy_d2h(ctx, MA_ENGINE_D2H, out_host[i], dout[k], nb);
+            const int rc = ma_engine_d2h_pieces(ctx, MA_ENGINE_D2H, out_host[i], dout[k], nb, cuts_out.data(), nband, [&](int b) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return failed != MA_OK || launched > (long long)i * nband + b; });
+                    if (failed != MA_OK) return failed;
+                }
+                if (TRACE) fprintf(stderr, "[pages] %8.2f down p%d b%d (issued)\n", now_ms(), i, b);
+                return ma_engine_wait(ctx, MA_ENGINE_D2H, ev_k[(size_t)k * nband + b]);
+            });
             std::lock_guard<std::mutex> lk(mu);
             if (rc != MA_OK) { fail(rc); return; }
+            if (TRACE) fprintf(stderr, "[pages] %8.2f down p%d complete\n", now_ms(), i);
             downloaded = i + 1;
             cv.notify_all();
         }
     });
     const float2* f = (const float2*)flow;
-    dim3 grid((W + 255) / 256, (H + WARP_ROWS - 1) / WARP_ROWS), block(256);
-    for (int i = 0; i < n_pages; i++) {
-        const int k = i % ns;
+    const dim3 block(256);
+    for (long long u = 0; u < n_units; u++) {
+        const int i = (int)(u / nband), b = (int)(u % nband), k = i % ns;
         {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return failed != MA_OK || uploaded > i; });
+            cv.wait(lk, [&] { return failed != MA_OK || uploaded > u; });
             if (failed != MA_OK) break;
         }
-        hipError_t e = hipStreamWaitEvent(ctx->stream, ev_up[k], 0);
+        const int y0 = band_begin(b), y1 = band_end(b);
+        const dim3 grid((W + 255) / 256, (y1 - y0 + WARP_ROWS - 1) / WARP_ROWS);
+        hipError_t e = hipStreamWaitEvent(ctx->stream, ev_up[(size_t)k * nband + b], 0);
         if (e == hipSuccess) {
-            if (dtype == MA_U8) hipLaunchKernelGGL((warp_tiled_kernel<uint8_t, false>), grid, block, 0, ctx->stream, (const uint8_t*)din[k], g, f, (uint8_t*)dout[k], (float*)nullptr, (unsigned*)nullptr, 0, 0);
-            else if (dtype == MA_U16) hipLaunchKernelGGL((warp_tiled_kernel<uint16_t, false>), grid, block, 0, ctx->stream, (const uint16_t*)din[k], g, f, (uint16_t*)dout[k], (float*)nullptr, (unsigned*)nullptr, 0, 0);
-            else hipLaunchKernelGGL((warp_tiled_kernel<float, false>), grid, block, 0, ctx->stream, (const float*)din[k], g, f, (float*)dout[k], (float*)nullptr, (unsigned*)nullptr, 0, 0);
+            if (dtype == MA_U8) hipLaunchKernelGGL((warp_band_kernel<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)din[k], g, f, (uint8_t*)dout[k], y0, y1);
+            else if (dtype == MA_U16) hipLaunchKernelGGL((warp_band_kernel<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)din[k], g, f, (uint16_t*)dout[k], y0, y1);
+            else hipLaunchKernelGGL((warp_band_kernel<float>), grid, block, 0, ctx->stream, (const float*)din[k], g, f, (float*)dout[k], y0, y1);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipEventRecord(ev_k[k], ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ev_k[(size_t)k * nband + b], ctx->stream);
+        if (TRACE) fprintf(stderr, "[pages] %8.2f kern p%d b%d\n", now_ms(), i, b);
         std::lock_guard<std::mutex> lk(mu);
         if (e != hipSuccess) {
-            ma_set_error("warp of page %d failed: %s", i, hipGetErrorString(e));
+            ma_set_error("warp of page %d (rows %d..%d) failed: %s", i, y0, y1, hipGetErrorString(e));
             fail(MA_EHIP);
             break;
         }
-        launched = i + 1;
+        launched = u + 1;
         cv.notify_all();
     }
     up.join();
     down.join();
+    if (TRACE) fprintf(stderr, "[pages] %8.2f joined\n", now_ms());
     (void)hipStreamSynchronize(ctx->stream);
     cleanup();
+    if (TRACE) fprintf(stderr, "[pages] %8.2f cleaned\n", now_ms());
     if (failed != MA_OK) {
         ma_set_error("%s", what.c_str());
         return failed;

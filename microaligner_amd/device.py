@@ -316,6 +316,10 @@ class Context:
         self._resident.remember(arr, d)
         return d
 
+    def is_resident(self, arr):
+        """Whether asdevice(arr) would find the host array in HBM already (no upload)."""
+        return isinstance(arr, DeviceArray) or self._resident.lookup(np.ascontiguousarray(arr)) is not None
+
     def _release(self, ptr, bucket):
         with self._host_lock:
             if self._closed:

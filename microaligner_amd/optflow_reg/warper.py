@@ -10,6 +10,8 @@ from ..device import DeviceArray, get_context
 
 
 class Warper:
+    HOST_BANDED_MIN = 64 << 20   # bytes; below this a page is a band or two and the plain upload / warp / download is as fast
+
     def __init__(self):
         self.image = np.array([])
         self.flow = np.array([])
@@ -23,9 +25,19 @@ class Warper:
             raise ValueError("No flow provided")
         ctx = get_context()
         like = self.image
+        if np.ndim(like) != 2:
+            raise ValueError(f"Expected 2D grayscale image, got shape {np.shape(like)}")
+        if isinstance(like, np.ndarray) and like.nbytes >= self.HOST_BANDED_MIN and not ctx.is_resident(like):
+            # a large host page that is not in HBM yet (the reference's own per-page loop, __main__.py:288-302, kept by a
+            # caller who only swapped the import): the page-warp driver moves it in bands of tile rows, so upload,
+            # kernel and download of the one page overlap
+            flow = ctx.asdevice(self.flow)
+            out = ctx.host_empty(like.shape, like.dtype)
+            ctx.warp_pages([like], flow, self.tile_size, self.overlap, [out])
+            self.image = np.array([])
+            self.flow = np.array([])
+            return out
         img, flow = ctx.asdevice(self.image), ctx.asdevice(self.flow)
-        if img.ndim != 2:
-            raise ValueError(f"Expected 2D grayscale image, got shape {img.shape}")
         out = ctx.warp(img, flow, self.tile_size, self.overlap)
         # like the reference (warper.py:41,45) the inputs are consumed
         self.image = np.array([])

@@ -71,18 +71,22 @@ def test_numpy_mean_replica_is_bit_identical():
     assert lib.ma_host_np_mean(None, 3, None) == _lib.MA_EINVAL
 
 
-def test_host_copy_pool_copies_every_byte():
-    """The host threads that fill / drain the page-locked staging chunks of the transfer engines (ma_api.hip, CopyPool):
-    sizes around the slice boundaries, odd sizes and offsets, repeated calls from two threads at once."""
+@pytest.mark.parametrize("fn", ["ma_host_parallel_copy", "ma_host_stream_copy"])
+def test_host_copy_pool_copies_every_byte(fn):
+    """The host threads that fill / drain the page-locked staging chunks of the transfer engines (ma_api.hip, CopyPool; the
+    drain writes with non-temporal stores): sizes around the slice boundaries, odd sizes and offsets (unaligned heads and
+    tails of the 16-byte stores), repeated calls from two threads at once."""
     import threading
     from microaligner_amd import _lib
     lib = _lib.load()
+    copy = getattr(lib, fn)
     rng = np.random.default_rng(1)
     src = rng.integers(0, 256, (40 << 20) + 977, dtype=np.uint8)
-    for n in (0, 1, 4095, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, (8 << 20) + 13, (32 << 20), src.size - 5):
-        dst = np.zeros(n + 64, np.uint8)
-        _lib.check(lib.ma_host_parallel_copy(dst.ctypes.data + 3, src.ctypes.data + 5, n))
-        assert np.array_equal(dst[3:3 + n], src[5:5 + n]) and not dst[:3].any() and not dst[3 + n:].any(), n
+    for n in (0, 1, 4095, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, (8 << 20) + 13, (32 << 20), src.size - 21):
+        for do, so in ((3, 5), (0, 0), (16, 1), (15, 16)):
+            dst = np.zeros(n + 64, np.uint8)
+            _lib.check(copy(dst.ctypes.data + do, src.ctypes.data + so, n))
+            assert np.array_equal(dst[do:do + n], src[so:so + n]) and not dst[:do].any() and not dst[do + n:].any(), (n, do, so)
     errs = []
 
     def hammer(seed):
@@ -91,7 +95,7 @@ def test_host_copy_pool_copies_every_byte():
             n = int(r.integers(1 << 20, 24 << 20))
             off = int(r.integers(0, src.size - n))
             d = np.empty(n, np.uint8)
-            lib.ma_host_parallel_copy(d.ctypes.data, src.ctypes.data + off, n)
+            copy(d.ctypes.data, src.ctypes.data + off, n)
             if not np.array_equal(d, src[off:off + n]):
                 errs.append((seed, n, off))
 
@@ -101,7 +105,7 @@ def test_host_copy_pool_copies_every_byte():
     for t in th:
         t.join()
     assert not errs
-    assert lib.ma_host_parallel_copy(None, None, 8) == _lib.MA_EINVAL
+    assert copy(None, None, 8) == _lib.MA_EINVAL
 
 
 def test_register_entry_rejects_bad_parameters_without_a_device():

@@ -438,6 +438,83 @@ def test_page_warp_driver_matches_single_page_warps(ctx):
         w.warp_pages([pages[0][:10]])
 
 
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
+@pytest.mark.parametrize("H,W,tile,ov", [(333, 290, 100, 12), (407, 130, 50, 40), (200, 300, 64, 0), (96, 257, 0, 0),
+                                         (301, 99, 300, 30)])
+def test_page_warp_driver_in_bands_of_one_tile_row(ctx, dtype, H, W, tile, ov):
+    """The driver's unit is a band of whole tile rows (an output pixel reads only its own window, warper.py:29-76): with the
+    band size forced down to one tile row, every band boundary, the ragged last band, overlaps larger than half a tile and
+    the untiled warp (one band) against the oracle -- displacements large enough to reach across the window borders."""
+    from microaligner_amd import _lib as L
+    rng = np.random.default_rng(H + tile)
+    pages = [(rng.random((H, W)) * (255 if dtype == np.uint8 else 60000)).astype(dtype) for _ in range(4)]
+    from scipy.ndimage import gaussian_filter
+    flow = np.stack([gaussian_filter(rng.standard_normal((H, W)), 5) * 150, gaussian_filter(rng.standard_normal((H, W)), 5) * 150],
+                    -1).astype(np.float32)
+    before = ctx.get_option(L.MA_OPT_WARP_BAND_BYTES)
+    assert before == 32 << 20
+    ctx.set_option(L.MA_OPT_WARP_BAND_BYTES, 1)
+    try:
+        w = Warper()
+        w.tile_size, w.overlap = tile, ov
+        w.flow = flow
+        ctx.transfer_stats(reset=True)
+        out = w.warp_pages(pages)
+        up, down = ctx.transfer_stats()
+    finally:
+        ctx.set_option(L.MA_OPT_WARP_BAND_BYTES, before)
+    def expected(p):
+        if tile:
+            return RO.warp(p, flow, tile, ov)
+        mp = np.negative(flow)                      # one window: the whole page
+        mp[:, :, 0] += np.arange(W)
+        mp[:, :, 1] += np.arange(H).reshape(-1, 1)
+        return RO.O.remap(p, mp)
+    for p, o in zip(pages, out):
+        assert np.array_equal(o, expected(p))
+    # every source and result row crosses the link exactly once, however the page is cut
+    nb = pages[0].nbytes
+    assert up == flow.nbytes + 4 * nb and down == 4 * nb
+    # the default band size gives the same pages
+    w.flow = flow
+    for a, b in zip(out, w.warp_pages(pages)):
+        assert np.array_equal(a, b)
+
+
+def test_warp_of_a_large_host_page_takes_the_banded_driver(ctx, monkeypatch):
+    """Warper.warp() of a host page that is not in HBM yet (the reference's per-page loop): through the page-warp driver
+    (bands of tile rows), same pixels as the resident path; a page that IS resident keeps the plain device warp."""
+    H, W = 1100, 1000                           # above the resident cache's minimum size
+    rng = np.random.default_rng(8)
+    page = rng.integers(0, 65535, (H, W)).astype(np.uint16)
+    dx, dy = synthetic.displacement(H, W)
+    flow = np.stack([dx, dy], -1).astype(np.float32) * 3
+    exp = RO.warp(page, flow, 150, 20)
+    from microaligner_amd import _lib as L
+    monkeypatch.setattr(Warper, "HOST_BANDED_MIN", 1 << 16)
+    calls = []
+    orig = type(ctx).warp_pages
+    monkeypatch.setattr(type(ctx), "warp_pages", lambda self, *a, **k: (calls.append(len(a[0])), orig(self, *a, **k))[1])
+    ctx.set_option(L.MA_OPT_WARP_BAND_BYTES, 1)
+    try:
+        w = Warper()
+        w.tile_size, w.overlap = 150, 20
+        w.image, w.flow = page.copy(), flow
+        got = w.warp()
+        assert calls == [1] and isinstance(got, np.ndarray) and np.array_equal(got, exp)
+        assert len(w.image) == 0 and len(w.flow) == 0          # inputs consumed like the reference (warper.py:41,45)
+        page.setflags(write=False)                             # an immutable host array is remembered once uploaded
+        dpage = ctx.asdevice(page)                             # now resident: no driver, no second upload
+        w.image, w.flow = page, flow
+        ctx.transfer_stats(reset=True)
+        got2 = w.warp()
+        assert calls == [1] and np.array_equal(got2, exp)
+        assert ctx.transfer_stats()[0] == flow.nbytes          # the (writable) flow travels, the page does not
+        del dpage
+    finally:
+        ctx.set_option(L.MA_OPT_WARP_BAND_BYTES, 32 << 20)
+
+
 def test_sharded_page_warps_fill_the_callers_rows(ctx, tmp_path):
     """parallel.warp_pages: pages dealt to the ranks (one rank here), loaders evaluated by their owner, results written in
     place into the rows of an array every rank can map (a .npy memory map: the output file of the pipeline)."""
