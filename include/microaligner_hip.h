@@ -258,8 +258,11 @@ int ma_warp_tiled_flowcells(ma_ctx* ctx, const void* img, int dtype, int H, int 
 
 /* Page-warp driver, warp_and_save_pages (__main__.py:288-302, 427-433): warps n_pages HOST images (the channel
  * and z pages of one cycle) with ONE device-resident flow, writing into caller-provided HOST buffers (e.g. rows
- * of the memmapped output TIFF).  H2D, kernel and D2H of consecutive pages overlap on internal streams.
- * Synchronous: returns when every output page is complete. */
+ * of the memmapped output TIFF).  Upload, kernel and download overlap on the ctx's three engines, in BANDS of whole
+ * tile rows (MA_OPT_WARP_BAND_BYTES): a window never reads outside itself (warper.py:29-76), so a band runs as soon as
+ * its source rows have arrived -- also within a single page (n_pages == 1 is Warper.warp() of a host image).  Pageable
+ * and page-locked buffers are both accepted, per page.  MICROALIGNER_TRACE_PAGES=1 prints the timeline of the three
+ * host threads to stderr.  Synchronous: returns when every output page is complete. */
 int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* out_host, int n_pages, int dtype,
                        int H, int W, const float* flow, int tile, int overlap);
 
