@@ -233,6 +233,57 @@ def cpu_baseline(sample, params):
                       f"tile cutting / stitching is single-threaded numpy as in the reference"}
 
 
+def page_warp_leg(n_pages, H, W, tile, overlap):
+    """SURVEY 8f-1, warp_and_save_pages (__main__.py:288-302): one device-resident flow applied to `n_pages` uint16 host pages
+    (the pipeline's page dtype), pageable numpy arrays in and out, every result page touched before the clock starts.  Two
+    callers: Warper.warp_pages (the driver with all pages in hand) and the reference's own loop, one Warper.warp() per
+    page.  PCIe inclusive by nature; informational."""
+    import numpy as np
+    from microaligner_amd import Warper
+    from microaligner_amd.device import get_context
+    ctx = get_context()
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 65535, (H, W), dtype=np.uint16)
+    pages = [base ^ np.uint16(257 * k) for k in range(n_pages)]
+    out = [np.ones_like(base) for _ in range(n_pages)]
+    flow = np.empty((H, W, 2), np.float32)
+    flow[..., 0] = 3.3 + np.linspace(-2.0, 2.0, W, dtype=np.float32)
+    flow[..., 1] = -2.1 + np.linspace(-1.5, 1.5, H, dtype=np.float32)[:, None]
+    dflow = ctx.asdevice(flow)
+    del flow
+    w = Warper()
+    w.tile_size, w.overlap = tile, overlap
+    w.flow = dflow
+    w.warp_pages(pages[:3], out[:3])        # device slots, staging rings and copy threads exist from here on
+    ctx.transfer_stats(reset=True)
+    t0 = time.perf_counter()
+    w.warp_pages(pages, out)
+    t_drv = time.perf_counter() - t0
+    up, down = ctx.transfer_stats(reset=True)
+
+    def loop(k):
+        for i in range(k):
+            w2 = Warper()
+            w2.tile_size, w2.overlap = tile, overlap
+            w2.image, w2.flow = pages[i], dflow
+            res = w2.warp()
+        return res
+    loop(min(3, n_pages))                   # the pool's page-locked result buffers exist from here on
+    t0 = time.perf_counter()
+    last = loop(n_pages)
+    t_loop = time.perf_counter() - t0
+    same = bool(np.array_equal(last, out[n_pages - 1]))
+    px = n_pages * H * W
+    return {"value": round(px / t_drv / 1e6, 1), "unit": "Mpix/s", "pages": n_pages, "page": f"{H}x{W} uint16",
+            "ms_per_page": round(t_drv / n_pages * 1e3, 2),
+            "pcie_gb_s_both_directions": round((up + down) / t_drv / 1e9, 1),
+            "per_page_warp_loop": {"value": round(px / t_loop / 1e6, 1), "unit": "Mpix/s",
+                                   "ms_per_page": round(t_loop / n_pages * 1e3, 2), "same_pixels_as_driver": same},
+            "what": "Warper.warp_pages: one resident flow, pageable numpy pages in, pageable numpy pages out (upload, kernel and "
+                    "download overlapped in bands of tile rows on the three engines); per_page_warp_loop: the reference's loop, "
+                    "one Warper.warp() per page (the same driver, one page per call, page-locked result from the pool)"}
+
+
 def lanes_leg(lanes, steps, device, dref, dmov, params, tile, overlap):
     """Seconds per pair with `lanes` pairs in flight (each lane: own context, `steps` register()+warp() passes)."""
     import threading
@@ -453,6 +504,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="pairs in flight for the informational multi-lane leg (0: skip)")
     ap.add_argument("--stream-pairs", type=int, default=12,
                     help="distinct pairs of the informational numpy -> numpy stream leg (parallel.stream_pairs; 0: skip)")
+    ap.add_argument("--page-warps", type=int, default=8,
+                    help="uint16 pages of the informational page-warp leg (SURVEY 8f-1: Warper.warp_pages and the per-page "
+                         "Warper.warp() loop, numpy in -> numpy out; 0: skip)")
     ap.add_argument("--no-shared-results", action="store_true",
                     help="N > 1: skip writing every rank's last flow / warped image into the node-wide shared array")
     ap.add_argument("--no-companion", action="store_true",
@@ -820,6 +874,11 @@ def main():
             informational(V, "muladd_fma", leg_muladd_fma)
             if reg.use_dog and not args.dog_fused:
                 informational(V, "dog_fma", leg_dog_fma)
+            if args.page_warps > 0:
+                # before the lanes leg: that one closes its contexts, and the driver clears released VRAM on the DMA engines
+                # -- for about a second per 25 GiB every hipMemcpy runs at 30 instead of 57 GB/s (profiles/r04_notes.md,
+                # tools/ubench_d2h_after_work.hip).  A pipeline keeps its contexts and pooled buffers and does not see that.
+                informational(V, "page_warp", lambda: page_warp_leg(args.page_warps, H, W, reg.tile_size, reg.overlap))
             if args.lanes > 1 and inv_affine is None:
                 informational(V, f"lanes{args.lanes}", leg_lanes)
         if world == 1 and not args.no_cpu_baseline and not args.pairs_total:
