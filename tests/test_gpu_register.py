@@ -481,6 +481,40 @@ def test_page_warp_driver_in_bands_of_one_tile_row(ctx, dtype, H, W, tile, ov):
         assert np.array_equal(a, b)
 
 
+def test_page_warp_driver_takes_page_locked_and_pageable_buffers_page_by_page(ctx):
+    """Every page and every result may be page-locked (Context.host_empty: copied by the DMA engine directly) or pageable
+    (staged through the engines' chunks) independently; sizes above the staging threshold (4 MiB) so that both paths run,
+    several staging chunks per page with the chunk boundaries falling inside bands."""
+    H, W = 2600, 1500                                   # 7.8 MB uint16 pages
+    rng = np.random.default_rng(21)
+    flow = np.stack([synthetic.displacement(H, W)[0] * 4, synthetic.displacement(H, W)[1] * 4], -1).astype(np.float32)
+    pages, outs = [], []
+    for k in range(5):
+        p = rng.integers(0, 65535, (H, W)).astype(np.uint16)
+        if k % 2:
+            q = ctx.host_empty((H, W), np.uint16, limit=8)
+            q[...] = p
+            p = q
+        pages.append(p)
+        outs.append(ctx.host_empty((H, W), np.uint16, limit=8) if k in (0, 1, 4) else np.empty((H, W), np.uint16))
+    from microaligner_amd import _lib as L
+    w = Warper()
+    w.tile_size, w.overlap = 400, 60
+    w.flow = flow
+    ref = [ctx.warp(ctx.asdevice(np.array(p)), ctx.asdevice(flow), 400, 60).numpy() for p in pages]
+    for band in (1, 32 << 20):
+        ctx.set_option(L.MA_OPT_WARP_BAND_BYTES, band)
+        try:
+            for o in outs:
+                o[...] = 0
+            w.warp_pages(pages, out=outs)
+        finally:
+            ctx.set_option(L.MA_OPT_WARP_BAND_BYTES, 32 << 20)
+        for k, (o, r) in enumerate(zip(outs, ref)):
+            assert np.array_equal(o, r), (band, k)
+    assert np.array_equal(ref[0], RO.warp(np.array(pages[0]), flow, 400, 60))
+
+
 def test_warp_of_a_large_host_page_takes_the_banded_driver(ctx, monkeypatch):
     """Warper.warp() of a host page that is not in HBM yet (the reference's per-page loop): through the page-warp driver
     (bands of tile rows), same pixels as the resident path; a page that IS resident keeps the plain device warp."""
