@@ -265,6 +265,11 @@ int ma_warp_tiled_flowcells(ma_ctx* ctx, const void* img, int dtype, int H, int 
  * host threads to stderr.  Synchronous: returns when every output page is complete. */
 int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* out_host, int n_pages, int dtype,
                        int H, int W, const float* flow, int tile, int overlap);
+/* The bands ma_warp_pages_host cuts a page into for a band size of band_bytes: band b holds the output rows
+ * [b * band_rows, min(H, (b + 1) * band_rows)) and runs once the source rows below min(H, (b + 1) * band_rows + overlap)
+ * are in HBM.  band_rows is a whole number of tile rows holding at least band_bytes (or H: one band; always for
+ * tile == 0).  Host-only (no ctx): the geometry can be checked without a GPU. */
+int ma_warp_pages_plan(int dtype, int H, int W, int tile, int overlap, size_t band_bytes, int* band_rows, int* n_bands);
 
 /* OptFlowRegistrator._merge_flow_in_tiles / merge_two_flows
  * (optflow_registrator.py:37-47,217-233): per window, out = flow2 if

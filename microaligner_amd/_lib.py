@@ -112,6 +112,7 @@ SIGNATURES.update({
     "ma_event_sync": (_i, [_vp, _vp]),
     "ma_host_parallel_copy": (_i, [_vp, _vp, _sz]),
     "ma_host_stream_copy": (_i, [_vp, _vp, _sz]),
+    "ma_warp_pages_plan": (_i, [_i, _i, _i, _i, _i, _sz, C.POINTER(_i), C.POINTER(_i)]),
     "ma_convert_f32": (_i, [_vp, _vp, _i, _sz, _vp]),
 })
 

@@ -572,6 +572,23 @@ int ma_warp_tiled_flowcells(ma_ctx* ctx, const void* img, int dtype, int H, int 
 // ty are complete once source rows < (ty + 1) * tile + overlap have arrived -- a single page (Warper.warp() of a
 // host image, the reference's own per-page loop) overlaps its own upload, kernel and download, and the first and
 // last page of a longer run lose only a band to filling and draining.
+int ma_warp_pages_plan(int dtype, int H, int W, int tile, int overlap, size_t band_bytes, int* band_rows, int* n_bands)
+{
+    MA_REQUIRE(band_rows && n_bands, "NULL argument");
+    MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
+    MA_REQUIRE(H > 0 && W > 0 && H <= 65535, "bad size");
+    MA_REQUIRE(tile >= 0 && overlap >= 0 && band_bytes > 0, "tile/overlap must be >= 0, the band size positive");
+    const size_t rowb = (size_t)W * ma_esize(dtype);
+    int rows = H;
+    if (tile > 0) {
+        const size_t tr = (band_bytes + (size_t)tile * rowb - 1) / ((size_t)tile * rowb);   // tile rows per band
+        rows = (int)std::min<size_t>((size_t)H, tr * (size_t)tile);
+    }
+    *band_rows = rows;
+    *n_bands = (H + rows - 1) / rows;
+    return MA_OK;
+}
+
 int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* out_host, int n_pages, int dtype,
                        int H, int W, const float* flow, int tile, int overlap)
 {
@@ -596,13 +613,8 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
     const size_t bytes = ma_align_up(nb, 256);
     // bands: whole tile rows, at least MA_OPT_WARP_BAND_BYTES each (32 MiB: a transfer below that no longer runs at the
     // link rate); an untiled warp (tile == 0: one window) is one band
-    const size_t MIN_BAND = ctx->warp_band_bytes;
-    int band_rows = H;
-    if (g.T > 0) {
-        const size_t tr = (MIN_BAND + (size_t)g.T * rowb - 1) / ((size_t)g.T * rowb);   // tile rows per band
-        band_rows = (int)std::min<size_t>((size_t)H, tr * (size_t)g.T);
-    }
-    const int nband = (H + band_rows - 1) / band_rows;
+    int band_rows = H, nband = 1;
+    MA_TRY(ma_warp_pages_plan(dtype, H, W, tile, overlap, ctx->warp_band_bytes, &band_rows, &nband));
     const long long n_units = (long long)n_pages * nband;
     MA_TRY(ma_ws_reserve(ctx, bytes * 2 * ns));  // device buffers come from the context workspace
     void *din[NS], *dout[NS];

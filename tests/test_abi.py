@@ -197,3 +197,43 @@ def test_a_missing_library_is_an_import_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libmicroaligner_hip.so"))
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_page_warp_band_plan_never_needs_a_row_that_has_not_arrived():
+    """ma_warp_pages_plan (the geometry of ma_warp_pages_host's bands): bands are whole tile rows and cover every output row
+    once; the window of every output row of band b (slicer.py:69-118: tile row ty spans rows ty*T - ov ... (ty+1)*T + ov)
+    ends at or before the source row the driver waits for before it launches the band; the band size is honoured."""
+    import ctypes as C
+    from microaligner_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(4)
+    cases = [(16384, 16384, 1000, 100, 32 << 20, _lib.MA_U16), (46300, 46700, 1000, 100, 32 << 20, _lib.MA_U16),
+             (333, 290, 100, 12, 1, _lib.MA_U8), (200, 300, 64, 0, 1, _lib.MA_F32), (96, 257, 0, 0, 1, _lib.MA_U8),
+             (407, 130, 50, 40, 1, _lib.MA_U16), (65535, 11, 7, 7, 1000, _lib.MA_U8), (1, 1, 5, 2, 1, _lib.MA_F32)]
+    for _ in range(300):
+        H, W = int(rng.integers(1, 5000)), int(rng.integers(1, 5000))
+        T = int(rng.integers(0, 1500))
+        cases.append((H, W, T, int(rng.integers(0, T + 1)), int(rng.choice([1, 1 << 16, 1 << 20, 32 << 20, 1 << 40])),
+                      int(rng.choice([_lib.MA_U8, _lib.MA_U16, _lib.MA_F32]))))
+    for H, W, T, ov, band_bytes, dt in cases:
+        rows, nb = C.c_int(), C.c_int()
+        _lib.check(lib.ma_warp_pages_plan(dt, H, W, T, ov, band_bytes, C.byref(rows), C.byref(nb)))
+        rows, nb = rows.value, nb.value
+        esz = {_lib.MA_U8: 1, _lib.MA_U16: 2, _lib.MA_F32: 4}[dt]
+        assert 1 <= rows <= H and nb == -(-H // rows), (H, W, T, ov, band_bytes)
+        if T == 0:
+            assert rows == H and nb == 1
+            continue
+        assert rows == H or rows % T == 0
+        if nb > 1:
+            assert rows * W * esz >= band_bytes                 # a band is at least the requested size ...
+            assert (rows - T) * W * esz < band_bytes            # ... and no tile row more than that takes
+        for b in range(nb):
+            y_last = min(H, (b + 1) * rows) - 1                 # the band's last output row and the tile row it lies in
+            window_end = min(H, (y_last // T + 1) * T + ov)     # one past the last source row that window reads
+            waited_for = H if b == nb - 1 else min(H, (b + 1) * rows + ov)
+            assert window_end <= waited_for, (H, W, T, ov, band_bytes, b)
+    r, n = C.c_int(), C.c_int()
+    assert lib.ma_warp_pages_plan(_lib.MA_U8, 0, 5, 5, 1, 1, C.byref(r), C.byref(n)) == _lib.MA_EINVAL
+    assert lib.ma_warp_pages_plan(_lib.MA_U8, 5, 5, 5, 1, 0, C.byref(r), C.byref(n)) == _lib.MA_EINVAL
+    assert lib.ma_warp_pages_plan(_lib.MA_U8, 5, 5, 5, 1, 1, None, C.byref(n)) == _lib.MA_EINVAL
