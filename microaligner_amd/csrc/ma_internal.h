@@ -93,6 +93,8 @@ struct ma_ctx {
 ma_ctx* ma_ctx_side(ma_ctx* ctx);
 void ma_stage_rings_destroy(ma_ctx* ctx);
 // stream of an engine (MA_ENGINE_*); nullptr + error set on failure
+// gridDim.y limit: kernels that put rows on the y axis take R rows per block, an image may have MA_GRID_Y_MAX * R rows
+constexpr int MA_GRID_Y_MAX = 65535;
 hipStream_t ma_engine_stream(ma_ctx* ctx, int engine);
 // One host <-> device copy on a transfer engine whose caller wants to act between its pieces (the bands of the page-warp
 // driver) without giving up the overlap of staging copy and DMA at every piece, as a sequence of ma_engine_memcpy_* calls

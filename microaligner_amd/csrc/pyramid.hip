@@ -204,7 +204,7 @@ static int pyr_down_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, 
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
     MA_REQUIRE(h > 0 && w > 0, "empty image");
     const int dh = (h + 1) / 2, dw = (w + 1) / 2;
-    MA_REQUIRE(dh <= 65535, "image too tall");
+    MA_REQUIRE(dh <= MA_GRID_Y_MAX * PD_ROWS, "image too tall");
     MA_HIP(hipSetDevice(ctx->device));
     dim3 grid(((dw + 1) / 2 + 255) / 256, (dh + PD_ROWS - 1) / PD_ROWS), block(256);
     const size_t nblk = (size_t)grid.x * grid.y;
@@ -240,7 +240,7 @@ int ma_pyr_down_minmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, vo
 int ma_pyr_up_flow(ma_ctx* ctx, const float* src, int h, int w, float scale, float* dst, int dh, int dw)
 {
     MA_REQUIRE(ctx && src && dst, "NULL argument");
-    MA_REQUIRE(h > 0 && w > 0 && dh > 0 && dw > 0 && dh <= 65535, "bad size");
+    MA_REQUIRE(h > 0 && w > 0 && dh > 0 && dw > 0 && (dh + 1) / 2 <= MA_GRID_Y_MAX * PU_ROWS, "bad size");
     MA_REQUIRE(abs(dw - w * 2) == dw % 2 && abs(dh - h * 2) == dh % 2,
                "cv2.pyrUp requires |dst - 2*src| == dst % 2 on both axes");
     MA_HIP(hipSetDevice(ctx->device));

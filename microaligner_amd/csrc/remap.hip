@@ -513,7 +513,8 @@ static int warp_tiled_impl(ma_ctx* ctx, const void* img, int dtype, int H, int W
 {
     MA_REQUIRE(ctx && img && flow && out, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
-    MA_REQUIRE(H > 0 && W > 0 && H <= 65535, "bad image size");
+    MA_REQUIRE(H > 0 && W > 0, "bad image size");
+    MA_REQUIRE(H <= MA_GRID_Y_MAX * WARP_ROWS, "image too tall");
     MA_REQUIRE(tile >= 0 && overlap >= 0, "tile/overlap must be >= 0");
     MaTiling g = ma_make_tiling(H, W, tile, overlap);
     MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
@@ -576,7 +577,7 @@ int ma_warp_pages_plan(int dtype, int H, int W, int tile, int overlap, size_t ba
 {
     MA_REQUIRE(band_rows && n_bands, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
-    MA_REQUIRE(H > 0 && W > 0 && H <= 65535, "bad size");
+    MA_REQUIRE(H > 0 && W > 0 && H <= MA_GRID_Y_MAX * WARP_ROWS, "bad size");
     MA_REQUIRE(tile >= 0 && overlap >= 0 && band_bytes > 0, "tile/overlap must be >= 0, the band size positive");
     const size_t rowb = (size_t)W * ma_esize(dtype);
     int rows = H;
@@ -594,7 +595,7 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
 {
     MA_REQUIRE(ctx && pages_host && out_host && flow, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
-    MA_REQUIRE(H > 0 && W > 0 && H <= 65535 && n_pages >= 0, "bad size");
+    MA_REQUIRE(H > 0 && W > 0 && H <= MA_GRID_Y_MAX * WARP_ROWS && n_pages >= 0, "bad size");
     MA_REQUIRE(tile >= 0 && overlap >= 0, "tile/overlap must be >= 0");
     MaTiling g = ma_make_tiling(H, W, tile, overlap);
     MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
@@ -755,7 +756,7 @@ int ma_merge_flows_tiled(ma_ctx* ctx, const float* flow1, const float* flow2, in
                          float* out)
 {
     MA_REQUIRE(ctx && flow1 && flow2 && out, "NULL argument");
-    MA_REQUIRE(H > 0 && W > 0 && H <= 65535, "bad image size");
+    MA_REQUIRE(H > 0 && W > 0 && H <= MA_GRID_Y_MAX * MERGE_ROWS, "bad image size");
     MA_REQUIRE(tile >= 0 && overlap >= 0, "tile/overlap must be >= 0");
     MaTiling g = ma_make_tiling(H, W, tile, overlap);
     MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
@@ -789,7 +790,7 @@ int ma_merge_flows_tiled_cells(ma_ctx* ctx, const float* flow1, const float* flo
                                const unsigned* cellkeys1, const unsigned* cellkeys2, float* out)
 {
     MA_REQUIRE(ctx && flow1 && flow2 && out && cellkeys1 && cellkeys2, "NULL argument");
-    MA_REQUIRE(H > 0 && W > 0 && H <= 65535, "bad image size");
+    MA_REQUIRE(H > 0 && W > 0 && H <= MA_GRID_Y_MAX * MERGE_ROWS, "bad image size");
     MA_REQUIRE(tile > 2 * overlap && overlap > 0, "flow cell maxima need tile > 2*overlap > 0");
     MaTiling g = ma_make_tiling(H, W, tile, overlap);
     MA_REQUIRE(g.Ph < 32767 && g.Pw < 32767, "cv2.remap requires window dimensions < 32767");
