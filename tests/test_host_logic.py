@@ -433,3 +433,73 @@ def test_numa_binding_follows_the_devices_local_cpulist(tmp_path):
         os.environ.pop("MICROALIGNER_BIND_NUMA", None)
         device.set_affinity(before)
     assert os.sched_getaffinity(0) == before
+
+
+def test_warper_routes_large_host_pages_through_the_page_driver(monkeypatch):
+    """Warper.warp() (warper.py:37-53 of the reference: image and flow in, warped image out, inputs consumed): a host page of
+    HOST_BANDED_MIN bytes or more that is not resident goes through Context.warp_pages as ONE page (upload, kernel and
+    download overlapped in bands); resident pages, device arrays and small pages take the plain device warp."""
+    from microaligner_amd.optflow_reg import warper as warper_mod
+    from microaligner_amd.device import DeviceArray
+    calls = []
+
+    class Dev:                                  # stands for a DeviceArray of the fake context
+        def __init__(self, a):
+            self.a, self.shape, self.ndim = a, a.shape, a.ndim
+
+        def numpy(self):
+            return self.a
+
+        def __len__(self):
+            return len(self.a)
+
+    class Ctx:
+        resident = set()
+
+        def is_resident(self, a):
+            return id(a) in self.resident
+
+        def asdevice(self, a):
+            return a if isinstance(a, Dev) else Dev(np.asarray(a))
+
+        def host_empty(self, shape, dtype):
+            return np.zeros(shape, dtype)
+
+        def warp_pages(self, pages, flow, tile, overlap, out):
+            calls.append(("pages", len(pages), tile, overlap))
+            out[0][...] = pages[0] + 1
+            return out
+
+        def warp(self, img, flow, tile, overlap):
+            calls.append(("device", tile, overlap))
+            return Dev(img.a + 1)
+
+    ctx = Ctx()
+    monkeypatch.setattr(warper_mod, "get_context", lambda: ctx)
+    monkeypatch.setattr(warper_mod, "DeviceArray", Dev)
+    monkeypatch.setattr(warper_mod.Warper, "HOST_BANDED_MIN", 4096)
+    big, small = np.ones((64, 64), np.uint16), np.ones((8, 8), np.uint16)
+    flow_big, flow_small = np.zeros((64, 64, 2), np.float32), np.zeros((8, 8, 2), np.float32)
+
+    def run(img, flow):
+        w = warper_mod.Warper()
+        w.tile_size, w.overlap = 30, 4
+        w.image, w.flow = img, flow
+        res = w.warp()
+        assert len(w.image) == 0 and len(w.flow) == 0
+        return res
+
+    res = run(big, flow_big)
+    assert calls == [("pages", 1, 30, 4)] and isinstance(res, np.ndarray) and (res == 2).all()
+    calls.clear()
+    assert (run(small, flow_small) == 2).all() and calls == [("device", 30, 4)]
+    calls.clear()
+    ctx.resident.add(id(big))
+    assert (run(big, flow_big) == 2).all() and calls == [("device", 30, 4)]
+    calls.clear()
+    res = run(Dev(big), flow_big)
+    assert isinstance(res, Dev) and calls == [("device", 30, 4)]
+    with pytest.raises(ValueError):
+        run(np.ones((4, 4, 3), np.uint8), np.zeros((4, 4, 2), np.float32))
+    with pytest.raises(ValueError):
+        run(np.array([]), flow_small)
