@@ -27,6 +27,8 @@ class Warper:
         like = self.image
         if np.ndim(like) != 2:
             raise ValueError(f"Expected 2D grayscale image, got shape {np.shape(like)}")
+        if isinstance(like, np.ndarray) and like.nbytes >= self.HOST_BANDED_MIN:
+            like = np.ascontiguousarray(like)      # a strided view is gathered once, here
         if isinstance(like, np.ndarray) and like.nbytes >= self.HOST_BANDED_MIN and not ctx.is_resident(like):
             # a large host page that is not in HBM yet (the reference's own per-page loop, __main__.py:288-302, kept by a
             # caller who only swapped the import): the page-warp driver moves it in bands of tile rows, so upload,
@@ -37,7 +39,7 @@ class Warper:
             self.image = np.array([])
             self.flow = np.array([])
             return out
-        img, flow = ctx.asdevice(self.image), ctx.asdevice(self.flow)
+        img, flow = ctx.asdevice(like), ctx.asdevice(self.flow)
         out = ctx.warp(img, flow, self.tile_size, self.overlap)
         # like the reference (warper.py:41,45) the inputs are consumed
         self.image = np.array([])
