@@ -742,6 +742,10 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
     up.join();
     down.join();
     if (TRACE) fprintf(stderr, "[pages] %8.2f joined\n", now_ms());
+    // also when a thread gave up early: nothing of this call may still be reading the caller's pages or writing its
+    // results once it has returned
+    (void)ma_engine_sync(ctx, MA_ENGINE_H2D);
+    (void)ma_engine_sync(ctx, MA_ENGINE_D2H);
     (void)hipStreamSynchronize(ctx->stream);
     cleanup();
     if (TRACE) fprintf(stderr, "[pages] %8.2f cleaned\n", now_ms());
