@@ -73,9 +73,11 @@ struct ma_ctx {
     // transfer engines (MA_ENGINE_H2D / MA_ENGINE_D2H): streams created on first use under `mu`
     hipStream_t engine[3] = {nullptr, nullptr, nullptr};
     std::mutex mu;
-    // staging rings per engine and direction ([engine][0] host -> device, [engine][1] device -> host): an engine is driven by
-    // one host thread at a time, so a ring is too
+    // staging rings per engine and direction ([engine][0] host -> device, [engine][1] device -> host)
     MaStageRing* stage[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    // a ring serves one copy at a time: a second host thread on the same engine and direction (ctx.asdevice() / .numpy() on
+    // the default context while parallel.stream_pairs drives it) waits its turn instead of sharing chunks
+    std::mutex stage_mu[3][2];
     // MA_OPT_COMPANION_STREAM
     bool companion = true;
     // MA_OPT_WARP_BAND_BYTES
@@ -114,6 +116,8 @@ int ma_engine_d2h_pieces(ma_ctx* ctx, int engine, void* dst_host, const void* sr
                          const MaPieceFn& before);
 // event i of the ctx's pool of timing-free events for ordering its two streams (created on demand; nullptr on failure)
 hipEvent_t ma_ctx_sync_event(ma_ctx* ctx, size_t i);
+// fixed indices beyond the events ma_optflow_register uses (2 per level + 1 <= 65)
+constexpr size_t MA_EV_WARP_PAGES = 125, MA_EV_COPY_IN = 126, MA_EV_COPY_OUT = 127;
 
 // device buffer from the ctx cache (64 KiB buckets); nullptr + error set on failure
 void* ma_pool_alloc(ma_ctx* ctx, size_t bytes);

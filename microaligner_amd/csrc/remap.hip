@@ -628,6 +628,17 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
         din[k] = (char*)ctx->ws + bytes * (2 * k);
         dout[k] = (char*)ctx->ws + bytes * (2 * k + 1);
     }
+    // The slots live in the context workspace, which kernels enqueued earlier on the compute stream (a tiled Farneback,
+    // a dog(), the NMI) may still be using: both transfer engines start behind everything the compute stream holds now
+    // (ma_ws_reserve itself synchronises only when the workspace has to grow).
+    {
+        hipEvent_t ws_idle = ma_ctx_sync_event(ctx, MA_EV_WARP_PAGES);
+        hipStream_t s_up = ma_engine_stream(ctx, MA_ENGINE_H2D), s_down = ma_engine_stream(ctx, MA_ENGINE_D2H);
+        if (!ws_idle || !s_up || !s_down) return MA_EHIP;
+        MA_HIP(hipEventRecord(ws_idle, ctx->stream));
+        MA_HIP(hipStreamWaitEvent(s_up, ws_idle, 0));
+        MA_HIP(hipStreamWaitEvent(s_down, ws_idle, 0));
+    }
     for (size_t e = 0; e < ev_up.size(); e++)
         if (hipEventCreateWithFlags(&ev_up[e], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev_k[e], hipEventDisableTiming) != hipSuccess) {

@@ -609,8 +609,10 @@ class Context:
         dt = _dt(pages[0].dtype)
         if any(p.shape != (H, W) or p.dtype != pages[0].dtype for p in pages):
             raise ValueError("all pages must have the same shape and dtype")
-        if flow.shape != (H, W, 2):
-            raise ValueError(f"flow must have shape {(H, W, 2)}")
+        if flow.shape != (H, W, 2) or flow.dtype != np.float32:
+            raise ValueError(f"flow must be float32 of shape {(H, W, 2)}, got {flow.dtype} {flow.shape}")
+        if getattr(flow, "ctx", self) is not self:
+            raise ValueError("flow belongs to another context")
         if out is None:
             out = [np.empty((H, W), pages[0].dtype) for _ in pages]
         if len(out) != len(pages) or any(o.shape != (H, W) or o.dtype != pages[0].dtype or not o.flags.c_contiguous
@@ -922,6 +924,17 @@ def set_affinity(cpus):
     except OSError:
         tids = [0]
     for tid in tids:
+        try:
+            # the library's staging-copy workers are pinned one per L3 domain (ma_api.hip CopyPool): they keep their
+            # placement, restricted to the new set where the two intersect
+            with open(f"/proc/self/task/{tid}/comm") as f:
+                if f.read().startswith("ma-copy-"):
+                    keep = os.sched_getaffinity(tid) & set(cpus)
+                    if keep:
+                        os.sched_setaffinity(tid, keep)
+                        continue
+        except OSError:
+            pass
         try:
             os.sched_setaffinity(tid, cpus)
         except OSError:

@@ -113,6 +113,11 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: b
     for scratch results; keep the name, and remove it with shared_array_unlink, when another process is to open it)."""
     import numpy as np
     rank, ws = world()
+    # SINGLE NODE: the file is created once and every rank maps that one file.  A launch that spans nodes has ranks whose
+    # /dev/shm is another machine's -- refuse it rather than fail in np.load after the barrier.
+    local_ws = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
+    if local_ws != ws:
+        raise RuntimeError(f"shared_array is node-wide: WORLD_SIZE {ws} spans more than this node's {local_ws} ranks")
     path = os.path.join(directory, name)
     shape = tuple(int(v) for v in shape)
     if rank == 0:

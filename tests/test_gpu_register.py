@@ -438,6 +438,28 @@ def test_page_warp_driver_matches_single_page_warps(ctx):
         w.warp_pages([pages[0][:10]])
 
 
+def test_page_warp_driver_starts_behind_kernels_that_still_use_the_workspace(ctx):
+    """The driver's device slots live in the context workspace.  A tiled Farneback that was only ENQUEUED (device arrays in,
+    device array out, no synchronisation) keeps its 20 planes per window there; page uploads that follow at once must not
+    land in them before its kernels are done (the upload engine is ordered behind the compute stream)."""
+    H = W = 1500
+    ref, mov = synthetic.make_pair(H, W, 77)
+    d_ref, d_mov = ctx.asdevice(ref), ctx.asdevice(mov)
+    tile, ov, win = 500, 50, 49
+    expected = ctx.farneback(d_mov, d_ref, win, 3, tile=tile, overlap=ov).numpy()      # synchronised by the download
+    rng = np.random.default_rng(3)
+    pages = [rng.integers(0, 65535, (H, W)).astype(np.uint16) for _ in range(6)]
+    flow = ctx.asdevice(np.zeros((H, W, 2), np.float32))
+    for _ in range(3):
+        d_flow = ctx.farneback(d_mov, d_ref, win, 3, tile=tile, overlap=ov)              # enqueued, still running ...
+        out = ctx.warp_pages(pages, flow, tile, ov)                                      # ... when the pages arrive
+        assert np.array_equal(d_flow.numpy(), expected)
+        for p, o in zip(pages, out):
+            assert np.array_equal(p, o)                                                  # zero flow: the identity
+    with pytest.raises(ValueError):
+        ctx.warp_pages(pages, ctx.asdevice(np.zeros((H, W, 2), np.float64)), tile, ov)
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32])
 @pytest.mark.parametrize("H,W,tile,ov", [(333, 290, 100, 12), (407, 130, 50, 40), (200, 300, 64, 0), (96, 257, 0, 0),
                                          (301, 99, 300, 30)])
