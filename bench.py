@@ -206,11 +206,37 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_baseline_opencv(sample, params):
+    """BASELINE.md section 2, plan A: the reference's orchestration over a LIVE cv2 (oracle/cv2_backend.py: the cv2 calls
+    as the reference writes them, Farneback windows and NMI chunks fanned out over one worker per hardware thread the way
+    utils.py:117-119 / flow_calc.py:93-97 fan them out over dask processes).  Raises ImportError where no cv2 imports."""
+    from microaligner_amd import synthetic
+    from oracle import cv2_backend
+    cores = os.cpu_count() or 1
+    ref, mov = synthetic.make_pair(sample, sample, 1)
+    stages = {}
+    t0 = time.perf_counter()
+    cv2_backend.register_over_cv2(ref, mov, workers=cores, stage_seconds=stages, **params)
+    dt = time.perf_counter() - t0
+    info = cv2_backend.build_summary()
+    return {"value": round(sample * sample / dt / 1e6, 3), "unit": "Mpix/s", "cores": cores,
+            "kind": "port" if info["standin"] else "opencv", "cpu": cpu_model(), "opencv": info,
+            "stage_seconds": {k: round(v, 2) for k, v in stages.items()},
+            "sample": f"{sample}x{sample} f32 pair, same parameters as the GPU workload, register()+warp(), {dt:.1f} s wall; "
+                      f"cv2 {info['version']} called as the reference calls it, {cores} windows / NMI chunks in flight "
+                      f"(threads: cv2 releases the GIL), tile cutting / stitching single-threaded numpy as in the reference"}
+
+
 def cpu_baseline(sample, params):
-    """The CPU oracle (oracle/, kind 'port') on a bounded sample of the same workload on every host core of this
-    box: Farneback windows, image rows (DOG, pyramids, remap) and NMI chunks fan out over OpenMP threads, one per
-    hardware thread -- the analogue of the reference's dask scheduler="processes" fan-out (utils.py:117-119,
-    flow_calc.py:93-97, similarity_scoring.py:44-48).  No cv2 on the box, so this is the restatement, not OpenCV."""
+    """The CPU baseline on a bounded sample of the same workload on every host core of this box.  Plan A when a cv2
+    imports: the orchestration over the real OpenCV (kind 'opencv', cpu_baseline_opencv).  Otherwise -- this image and the
+    GPU pool have no cv2 -- the CPU oracle (oracle/, kind 'port'): Farneback windows, image rows (DOG, pyramids, remap)
+    and NMI chunks fan out over OpenMP threads, one per hardware thread -- the analogue of the reference's dask
+    scheduler="processes" fan-out (utils.py:117-119, flow_calc.py:93-97, similarity_scoring.py:44-48)."""
+    try:
+        return cpu_baseline_opencv(sample, params)
+    except ImportError:
+        pass
     from microaligner_amd import synthetic
     from oracle import register_oracle as RO
     cores = os.cpu_count() or 1

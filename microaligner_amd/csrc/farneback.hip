@@ -495,20 +495,28 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v_stream(FbGeom g, 
 // Q = ceil((NW*R + 2m + 4) / 64): column chunks of the staged row tile
 // LAST: the final iteration only stores the centre crop of the flow; it is its own instantiation, so it carries
 // neither the code nor the registers of UpdateMatrices.
-template <int R, int NW, bool FUSED, int Q, bool LAST>
+// ROWS = 64: a lane is a row.  ROWS = 32: a wave is two half-waves of 32 rows, the upper one NW * R columns further right
+// (ds_read2_b32 is banked per group of 32 lanes, so the two halves never conflict): the same 112 output columns and the
+// same staged width per block with half the rows, half the waves and half the LDS -- four independent blocks per CU instead
+// of two, so that the memory phases of a block (staging, UpdateMatrices) more often find another block filtering.
+template <int R, int NW, bool FUSED, int Q, bool LAST, int ROWS>
 __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, int m, const float* __restrict__ taps,
                                                            float* __restrict__ ws, float* __restrict__ flow_out,
                                                            int nwin, int reach)
 {
     extern __shared__ float lds[];
-    constexpr int TXW = NW * R;           // output columns per block
+    static_assert(ROWS == 64 || ROWS == 32, "a wave covers 64 rows, or 32 rows twice");
+    constexpr int HALVES = 64 / ROWS;
+    constexpr int TXW = NW * R * HALVES;  // output columns per block
     constexpr int NT = 64 * NW;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const int row = lane & (ROWS - 1);                       // tile row of this lane in the filter and the solve
+    const int hcol = (lane / ROWS) * (NW * R);               // first output column of this lane's half-wave
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index: keeps row/column math on the SALU
     const int Ph = g.t.Ph, Pw = g.t.Pw;
     // x-fastest work list walked contiguously per XCD (see fb_blur_v): horizontally adjacent blocks share 2m columns
-    const int nbx = (Pw + TXW - 1) / TXW, nby = (Ph + 63) / 64;
+    const int nbx = (Pw + TXW - 1) / TXW, nby = (Ph + ROWS - 1) / ROWS;
     const int nslots = (int)(((nwin + 7) / 8) * 8);
     const int item = d_xcd_work_item(blockIdx.x, nbx * nby * nslots);
     const int bx = item % nbx, by = (item / nbx) % nby;
@@ -518,17 +526,17 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
     window_origin(g.t, g.tile0 + wl, oy, ox);
     window_extent(g, oy, ox, ey, ex);
     const FbRect need = needed_rect_h(g.t, oy, ox, reach);
-    const int x0 = (need.x0 & ~(NEED_XALIGN - 1)) + bx * TXW, y0 = need.y0 + by * 64;
+    const int x0 = (need.x0 & ~(NEED_XALIGN - 1)) + bx * TXW, y0 = need.y0 + by * ROWS;
     const int xend = min(ex, need.x1), yend = min(ey, need.y1);   // needed AND possibly non-zero
     if (x0 >= xend || y0 >= yend) return;
     constexpr int G = 2;  // guard columns on either side (d_sym_fir_slide contract)
     const int cols = TXW + 2 * m + 2 * G;
     const int lp = cols | 1;              // odd LDS pitch: lanes (rows) hit distinct banks
 
-    // Staging of one plane: 64/NW rows x Q column chunks per wave; every global load is issued before the first
+    // Staging of one plane: ROWS/NW rows x Q column chunks per wave; every global load is issued before the first
     // LDS store.  (Issuing plane ch+1's loads before plane ch is filtered -- register prefetch -- was measured: no gain
     // at 4 waves/SIMD, spills at 6.)
-    constexpr int RW = 64 / NW;
+    constexpr int RW = ROWS / NW;
     float v[RW][Q];
     // one buffer resource spans the window's 20 planes: plane and row offsets ride in SGPRs, each access needs
     // only a 32-bit lane offset (no 64-bit VALU address arithmetic)
@@ -573,7 +581,7 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
         __syncthreads();
         float acc[R];
         if (wave_needed) {
-            d_sym_fir_slide_pk<R, FUSED, false>(lds + lane * lp, G + m + w * R, m, taps, acc);
+            d_sym_fir_slide_pk<R, FUSED, false>(lds + row * lp + hcol, G + m + w * R, m, taps, acc);
         } else {
 #pragma unroll
             for (int r = 0; r < R; r++) acc[r] = 0.f;
@@ -598,7 +606,7 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
             const double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
             const float dx = (float)((g11 * h2 - g12 * h1) * idet);
             const float dy = (float)((g22 * h1 - g12 * h2) * idet);
-            tb[lane * TP + w * R + r] = (ma_f2){dx, dy};
+            tb[row * TP + hcol + w * R + r] = (ma_f2){dx, dy};
         }
     }
     __syncthreads();
@@ -612,10 +620,10 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
         // through a buffer resource that starts at this block's first image row (offsets stay below 2^31 for any
         // image the 32-bit pixel coordinates allow).
         float* frow = flow_out + (size_t)(oy + y0) * g.t.W * 2;
-        const long long fbytes = (long long)min(64, yend - y0) * g.t.W * 8;
+        const long long fbytes = (long long)min(ROWS, yend - y0) * g.t.W * 8;
         const __amdgpu_buffer_rsrc_t frsrc = __builtin_amdgcn_make_buffer_rsrc(
             frow, 0, (int)(fbytes < 0x7fffffffLL ? fbytes : 0x7fffffffLL), 0x00020000);
-        for (int p = tid; p < 64 * TXW; p += NT) {
+        for (int p = tid; p < ROWS * TXW; p += NT) {
             const int rh = p / TXW, c = p - rh * TXW;
             const int y = y0 + rh, x = x0 + c;
             if (y < yend && x >= need.x0 && x < xend) {
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
     } else {
         auto epilogue = [&](auto near_border_tag) {
             constexpr bool NEAR_BORDER = decltype(near_border_tag)::value;
-            for (int p = tid; p < 64 * TXW; p += NT) {
+            for (int p = tid; p < ROWS * TXW; p += NT) {
                 const int rh = p / TXW, c = p - rh * TXW;
                 const int y = y0 + rh, x = x0 + c;
                 if (y < yend && x >= need.x0 && x < xend) {
@@ -668,7 +676,7 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
             }
         };
         // the 5-px border attenuation of UpdateMatrices concerns only the outermost blocks of a window
-        const bool near_border = x0 < 5 || x0 + TXW > Pw - 5 || y0 < 5 || y0 + 64 > Ph - 5;
+        const bool near_border = x0 < 5 || x0 + TXW > Pw - 5 || y0 < 5 || y0 + ROWS > Ph - 5;
         if (near_border) epilogue(std::true_type{});
         else epilogue(std::false_type{});
     }
@@ -841,8 +849,14 @@ constexpr int BV_R = 14, BV_NW = 4;   // fb_blur_v: 64 columns x (NW*R) = 56 row
                                       // 49 tap pairs are 7 full groups of R/2 and the strip (158 rows) lets 4 blocks share a CU
 constexpr int BVS_NW = 8;             // fb_blur_v_stream: chunks of 8 x 14 = 112 rows, ring of 214 + 22 rows = 60 KB, 2 blocks / CU
                                       // (measured per launch: 4 waves 1.55 ms, 6 waves 1.70, 8 waves 1.53, 16 waves 1.84; tiled form 1.67)
-constexpr int BH_R = 14, BH_NW = 8;   // fb_blur_h_solve: 64 rows x 112 columns per block (56 KB tile, 2 blocks / CU, 4 waves / SIMD at
+#ifndef MA_BH_ROWS
+#define MA_BH_ROWS 64
+#endif
+constexpr int BH_ROWS = MA_BH_ROWS;   // rows per block of fb_blur_h_solve (64, or 32: half-wave rows)
+constexpr int BH_R = 14, BH_NW = 8 * BH_ROWS / 64;
+                                      // fb_blur_h_solve: 64 rows x 112 columns per block (56 KB tile, 2 blocks / CU, 4 waves / SIMD at
                                       // ~124 VGPRs; measured per launch: R 8 x 8 waves 2.142 ms, R 14 x 4 waves 2.227, R 14 x 8 waves 2.104)
+constexpr int BH_TXW = BH_NW * BH_R * (64 / BH_ROWS);
 constexpr size_t LDS_MAX = 160 * 1024;
 
 template <typename T, bool FUSED>
@@ -852,9 +866,9 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
     float* ws = (float*)ctx->ws;
     const int Ph = g.t.Ph, Pw = g.t.Pw;
     const size_t lds_v = (size_t)(BV_NW * BV_R + 2 * m + 4) * 64 * sizeof(float);
-    const int colsh = BH_NW * BH_R + 2 * m + 4;
-    size_t lds_h = (size_t)64 * (colsh | 1) * sizeof(float);
-    const size_t lds_t = (size_t)64 * (BH_NW * BH_R + 1) * 2 * sizeof(float);   // the flow on its way to the x-major epilogue
+    const int colsh = BH_TXW + 2 * m + 4;
+    size_t lds_h = (size_t)BH_ROWS * (colsh | 1) * sizeof(float);
+    const size_t lds_t = (size_t)BH_ROWS * (BH_TXW + 1) * 2 * sizeof(float);   // the flow on its way to the x-major epilogue
     if (lds_t > lds_h) lds_h = lds_t;
     const bool fast = m >= 1 && lds_v <= LDS_MAX && lds_h <= LDS_MAX && colsh <= 320;  // 320 = 5 chunks (winsize <= 253)
     // the LDS-staged kernels honour the active extent; the fallback kernels process whole windows
@@ -901,13 +915,13 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
             }
             {
                 MaProfScope ps(ctx, MA_K_BLUR_H_SOLVE, px_h[it]);
-                const long long items = (long long)((Pw + BH_NW * BH_R - 1) / (BH_NW * BH_R)) * ((Ph + 63) / 64) * ma_xcd_slots(nwin);
+                const long long items = (long long)((Pw + BH_TXW - 1) / BH_TXW) * ((Ph + BH_ROWS - 1) / BH_ROWS) * ma_xcd_slots(nwin);
                 // Q = 64-column chunks of the staged row tile (112 + 2m + 4 columns)
 #define MA_BLUR_H(QQ)                                                                                               \
     do {                                                                                                            \
-        if (last) hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, QQ, true>), dim3(ma_xcd_grid(items)),     \
+        if (last) hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, QQ, true, BH_ROWS>), dim3(ma_xcd_grid(items)),     \
                                      dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, flow_out, nwin, reach);  \
-        else hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, QQ, false>), dim3(ma_xcd_grid(items)),         \
+        else hipLaunchKernelGGL((fb_blur_h_solve<BH_R, BH_NW, FUSED, QQ, false, BH_ROWS>), dim3(ma_xcd_grid(items)),         \
                                 dim3(64 * BH_NW), lds_h, ctx->stream, g, m, taps, ws, flow_out, nwin, reach);       \
     } while (0)
                 if (colsh <= 192) MA_BLUR_H(3);

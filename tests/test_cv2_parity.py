@@ -175,57 +175,7 @@ def test_oracle_warp_affine_vs_cv2(dtype):
         np.testing.assert_allclose(got, exp, rtol=F32_RTOL, atol=1e-3)
 
 
-class _Cv2Prims:
-    """The primitives oracle/register_oracle.py composes, served by the real cv2 (NMI by scikit-learn when present,
-    else by the oracle's NMI, which is pinned to scikit-learn by tests/test_gpu_primitives.py)."""
-
-    @staticmethod
-    def set_threads(n):
-        pass
-
-    @staticmethod
-    def calc_optical_flow_farneback(prev, nxt, winsize, iterations, fused=False):
-        return cv_farneback(prev, nxt, winsize, iterations)
-
-    @staticmethod
-    def farneback_batch(prev_tiles, next_tiles, winsize, iterations, fused=False, nthreads=1):
-        return np.stack([cv_farneback(p, n, winsize, iterations) for p, n in zip(prev_tiles, next_tiles)])
-
-    @staticmethod
-    def remap(src, m):
-        return cv2.remap(src, np.ascontiguousarray(m, dtype=np.float32), None, cv2.INTER_LINEAR)
-
-    pyr_down = staticmethod(lambda img: cv2.pyrDown(img))
-    pyr_up = staticmethod(lambda img, dstsize=None: cv2.pyrUp(img, dstsize=dstsize))
-
-    @staticmethod
-    def dog(img, use_it=True, low_sigma=5, high_sigma=9, flags=0):
-        return cv_dog(img, low_sigma, high_sigma) if use_it else img
-
-    @staticmethod
-    def nmi_u8(a, b):
-        try:
-            from sklearn.metrics import normalized_mutual_info_score
-            return float(normalized_mutual_info_score(np.ravel(a), np.ravel(b)))
-        except ImportError:
-            return O.nmi_u8(a, b)
-
-    @classmethod
-    def nmi_u8_chunks(cls, a, b, chunk):
-        fa, fb = np.ravel(a), np.ravel(b)
-        return np.array([cls.nmi_u8(fa[i:i + chunk], fb[i:i + chunk]) for i in range(0, fa.size, chunk)])
-
-
-def register_over_cv2(ref, mov, **params):
-    """The oracle ORCHESTRATION (pinned by fixtures made with the reference's own classes) over the real cv2."""
-    saved = RO.O
-    RO.O = _Cv2Prims
-    try:
-        flow, reports = RO.register(ref, mov, **params)
-        warped = RO.warp(mov, flow, params.get("tile_size", 1000), params.get("overlap", 100))
-    finally:
-        RO.O = saved
-    return flow, reports, warped
+from oracle.cv2_backend import Cv2Prims as _Cv2Prims, register_over_cv2     # noqa: E402  (cv2 imports: checked above)
 
 
 E2E = dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True, tile_size=200, overlap=30)
