@@ -81,6 +81,12 @@ def algorithmic_bytes_per_px(kernel, iters, esz):
     return 0
 
 
+# own loads + stores per processed pixel where they differ from the algorithmic bytes (the window blurs: M in + V out;
+# V in + R0 + R1 + M out, or V in + flow out in the last iteration)
+OWN_IO_BYTES_PER_PX = {"blur_v": 40, "blur_h_solve": lambda iters: ((iters - 1) * 80 + 28) / iters}
+FP32_FLOP_PEAK_TF = 157.3
+
+
 def pmc_traffic(workload):
     """HBM bytes per step and kernel group from the newest committed rocprofv3 PMC summary of this very command
     (profiles/rNN_hbm_traffic_<workload>.json, tools/collect_profiles.sh: separate --pmc FETCH_SIZE / WRITE_SIZE
@@ -146,6 +152,15 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
     if traffic_per_step and name in traffic_per_step:
         traffic = round(traffic_per_step[name] * steps / rec["launches"])  # HBM bytes per launch (PMC)
     hbm = {"achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    own = OWN_IO_BYTES_PER_PX.get(name)
+    if callable(own):
+        own = own(iters)
+    if own:
+        # what this kernel's own loads and stores amount to: for the two window blurs that includes the
+        # separable intermediate V, which SURVEY 8d does not count as algorithmic but which does cross HBM
+        hbm["own_io_bytes_per_px"] = round(own, 2)
+        hbm["own_io_gbs"] = round(own * rec["px"] / sec / 1e9, 1)
+        hbm["own_io_frac"] = round(own * rec["px"] / sec / 1e9 / HBM_PEAK_GBS, 4)
     out = {"kernel": name, "bound": "hbm", **hbm, "traffic": traffic,
            "traffic_source": traffic_source if traffic is not None else None,
            "avg_launch_ms": round(rec["ms"] / rec["launches"], 4), "launches": rec["launches"],
@@ -171,6 +186,9 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
         peak_clk = VALU_LANES_PER_CLOCK * ghz * 1e9 / 1e12
         out.update({"bound": "valu", "achieved": round(tf, 2), "peak": round(peak_nom, 2), "unit": "TFLOP/s",
                     "frac": round(tf / peak_nom, 4),
+                    # the same arithmetic against the guide's FP32 FLOP peak (157.3 TFLOP/s: every lane-operation a fused
+                    # multiply-add counted as two) -- the unfused model cannot issue FMAs, so this view caps at 0.5
+                    "frac_flops_of_157TF": round(tf / FP32_FLOP_PEAK_TF, 4),
                     "peak_at_sustained_clock": round(peak_clk, 2), "frac_at_sustained_clock": round(tf / peak_clk, 4),
                     "clock_ghz": round(ghz, 3),
                     "clock_source": (f"{kernel_clock_source} (GRBM_GUI_ACTIVE of this kernel)" if kernel_clock else
@@ -815,9 +833,11 @@ def main():
                                                         "known matrix" if wl.get("affine") else None),
                        "parallelism": f"{pairs_per_step} independent pairs per step dealt round-robin to {world} rank(s), "
                                       f"one rank per GPU, {min(world, ndev)} GPU(s), no collective on the data path"},
-            "roofline": kernels.get(dominant),
-            "roofline_polyexp": kernels.get("polyexp_m0"),
-            "kernels": kernels,
+            # one compact row per kernel group; the full entries of the dominant kernel (`roofline`), the north-star kernel
+            # (`roofline_polyexp`) and the vertical pass (`roofline_blur_v`) close the line, where a tail reader sees them
+            "kernels": {k: {f: v[f] for f in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches",
+                                              "share_of_kernel_time", "px_per_launch") if f in v}
+                        for k, v in kernels.items()},
             "kernel_time_ms_per_step": round(total_kernel_ms / args.steps, 3),
             "kernel_time_note": "sum of the launch durations on BOTH streams of the context: the dog() of the reference and "
                                 "the moving image of every level run on a low-priority companion stream under the level "
@@ -914,6 +934,12 @@ def main():
             set_affinity(all_cpus)      # the CPU baseline uses every core of the host, not just the GPU's node
             sample = args.cpu_sample or (H if (os.cpu_count() or 1) >= 128 else 4096)
             informational(res, "cpu_baseline", lambda: cpu_baseline(min(sample, H), params))
+        for key, name in (("roofline_blur_v", "blur_v"), ("roofline_polyexp", "polyexp_m0")):
+            if name != dominant:
+                res[key] = kernels.get(name)
+        if dominant != "blur_h_solve":
+            res["roofline_blur_h_solve"] = kernels.get("blur_h_solve")
+        res["roofline"] = kernels.get(dominant)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

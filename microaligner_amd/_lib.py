@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# MICROALIGNER_HIP_LIB: another build of the same library (A/B timing of two builds on one box, tools/exp_lib_ab.sh)
+# MICROALIGNER_HIP_LIB: another build of the same library (A/B timing of two builds on one box, tools/ab_libs.sh)
 LIB_PATH = os.environ.get("MICROALIGNER_HIP_LIB") or os.path.join(_HERE, "libmicroaligner_hip.so")
 
 MA_U8, MA_U16, MA_F32 = 0, 1, 2
