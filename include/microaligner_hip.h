@@ -145,6 +145,14 @@ int ma_memcpy_d2h_async(ma_ctx* ctx, void* dst_host, const void* src, size_t byt
  * pageable array costs a first-touch page fault per 4 KiB on every call).  Not tied to a ctx. */
 int ma_host_alloc(size_t bytes, void** hptr);
 int ma_host_free(void* hptr);
+/* Page-lock memory the CALLER owns, in place (hipHostRegister): a node-wide shared result array
+ * (microaligner_amd.parallel.shared_array: the counterpart of the reference's memmapped output, __main__.py:116-132), a
+ * reused input buffer.  From then on transfers to and from it go by DMA directly -- no staging copy, one pass over host
+ * DRAM per byte instead of three, which is what an 8-rank node needs.  Registration pins the pages
+ * (cost ~ a first touch of every page): for buffers that live across many transfers, not for one-shot arrays.  The range
+ * must stay mapped until ma_host_unregister; each process registers its own mapping of shared memory. */
+int ma_host_register(void* hptr, size_t bytes);
+int ma_host_unregister(void* hptr);
 int ma_memset(ma_ctx* ctx, void* dst, int value, size_t bytes);
 
 /* ---- timing (HIP events on the ctx stream) ------------------------------ */

@@ -42,6 +42,8 @@ SIGNATURES = {
     "ma_memcpy_d2h_async": (_i, [_vp, _vp, _vp, _sz]),
     "ma_host_alloc": (_i, [_sz, C.POINTER(_vp)]),
     "ma_host_free": (_i, [_vp]),
+    "ma_host_register": (_i, [_vp, _sz]),
+    "ma_host_unregister": (_i, [_vp]),
     "ma_memset": (_i, [_vp, _vp, _i, _sz]),
     "ma_event_create": (_i, [_vp, C.POINTER(_vp)]),
     "ma_event_destroy": (_i, [_vp, _vp]),

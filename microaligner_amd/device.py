@@ -942,6 +942,31 @@ def set_affinity(cpus):
     os.sched_setaffinity(0, cpus)
 
 
+def host_register(arr):
+    """Page-lock `arr`'s memory in place (ma_host_register): transfers to and from it then go by DMA directly instead of
+    through the staging chunks -- one pass over host DRAM per byte instead of three.  For arrays that live across many
+    transfers (parallel.shared_array results, reused input buffers); registration itself costs about a first touch of
+    every page.  Returns True when the range is page-locked now, False when the runtime refused (no device in this
+    process, pages that cannot be pinned -- a memmap of a file on disk): the array then goes through the staging path as
+    before.  The registration ends with the array (weakref finalizer)."""
+    import weakref
+    a = np.asarray(arr)
+    if a.nbytes == 0 or not a.flags.c_contiguous:
+        return False
+    lib = L.load()
+    ptr = a.ctypes.data
+    if lib.ma_host_register(C.c_void_p(ptr), C.c_size_t(a.nbytes)) != L.MA_OK:
+        return False
+    base = arr
+    while isinstance(getattr(base, "base", None), np.ndarray):     # the finalizer hangs on the object that owns the memory
+        base = base.base
+    try:
+        weakref.finalize(base, lib.ma_host_unregister, C.c_void_p(ptr))
+    except TypeError:                                                # not weak-referenceable: stays registered
+        pass
+    return True
+
+
 def device_count():
     n = C.c_int()
     L.load().ma_device_count(C.byref(n))

@@ -102,7 +102,7 @@ def _run_local(units: Sequence, mine: List[int], fn: Callable, lanes: int):
     return results
 
 
-def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: bool = False):
+def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: bool = False, page_locked: bool = True):
     """A node-wide array every rank maps: rank 0 creates `directory/name` (POSIX shared memory by default; any path
     works, e.g. next to the output TIFF), the others open it after a barrier.  COLLECTIVE (every rank calls it with
     the same arguments).  This is where results of a sharded run go instead of being pickled through the control plane:
@@ -110,7 +110,12 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: b
     writes every page straight into its memmapped output (__main__.py:116-132).
     unlink=True: the name is removed as soon as every rank has mapped the file -- the mappings stay valid, the memory goes
     back when the last rank drops its array or dies, and nothing is left behind in /dev/shm whatever happens later (use it
-    for scratch results; keep the name, and remove it with shared_array_unlink, when another process is to open it)."""
+    for scratch results; keep the name, and remove it with shared_array_unlink, when another process is to open it).
+    page_locked=True: every rank page-locks ITS mapping in place (device.host_register) when it has a HIP device, so that
+    its download engine writes results by DMA straight into the shared memory -- no staging copy: per result byte one
+    pass over host DRAM instead of three, which is what keeps eight ranks within the host's memory bandwidth (DESIGN.md
+    section 6).  Where the runtime refuses (no device: gloo tests, --dry-run; a file on disk) the array is pageable as before;
+    `arr_is_page_locked(arr)` tells."""
     import numpy as np
     rank, ws = world()
     # SINGLE NODE: the file is created once and every rank maps that one file.  A launch that spans nodes has ranks whose
@@ -132,7 +137,33 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: b
         _barrier()
         if rank == 0:
             os.unlink(path)
+    if page_locked:
+        _page_lock(arr)
     return arr
+
+
+_PAGE_LOCKED = {}      # id(memmap) -> True, dropped with the array
+
+
+def _page_lock(arr):
+    """Best effort: only where a device exists in this process (the registration needs the HIP runtime)."""
+    try:
+        from . import device
+        if device.device_count() <= 0:
+            return False
+        ok = device.host_register(arr)
+    except Exception:   # noqa: BLE001 -- no library / no device: the staging path serves the array
+        return False
+    if ok:
+        import weakref
+        _PAGE_LOCKED[id(arr)] = True
+        weakref.finalize(arr, _PAGE_LOCKED.pop, id(arr), None)
+    return ok
+
+
+def arr_is_page_locked(arr) -> bool:
+    """True when shared_array page-locked this array's memory in this process."""
+    return bool(_PAGE_LOCKED.get(id(arr)))
 
 
 def shared_array_unlink(name: str, directory: str = "/dev/shm"):

@@ -95,3 +95,23 @@ def test_bench_launcher_propagates_a_rank_failure():
                         "--workload", "cfg1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_eight_rank_host_soak_runs_without_a_device():
+    """tools/host_soak.py: eight processes, each bound to its share of the host's NUMA nodes, cycle the
+    staging copies of the numpy -> numpy stream in both directions at once through the library's two copy pools -- no device
+    involved.  Here: a miniature (the numbers of the 2 x 64-core GPU host are in DESIGN.md); every rank must have moved bytes
+    in both directions and the report must carry the needed-vs-sustained fields."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_soak.py"), "--ranks", "8", "--scale", "0.004",
+                        "--seconds", "0.5", "--mode", "stream"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.strip().splitlines()]
+    assert "numa_nodes" in lines[0]
+    row = lines[1]
+    assert row["ranks"] == 8 and len(row["per_rank_in_gb_s"]) == 8 and len(row["per_rank_out_gb_s"]) == 8
+    assert min(row["per_rank_in_gb_s"]) > 0 and min(row["per_rank_out_gb_s"]) > 0
+    assert row["needed_in_gb_s"] == pytest.approx(8 * 2 * 16384 ** 2 * 4 / 0.075 / 1e9, rel=1e-3)
+    assert 0 < row["covers"]
