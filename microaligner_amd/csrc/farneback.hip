@@ -542,23 +542,21 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
     // only a 32-bit lane offset (no 64-bit VALU address arithmetic)
     const int plane4 = (int)(g.plane * sizeof(float));
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr(ws, g, wl, 0), 0, PL_COUNT * plane4, 0x00020000);
-    int xo[Q];       // lane byte offset of column chunk q (clamped into the active extent)
-    bool xz[Q];      // chunk column lies right of the active extent: V is exactly zero there
+    // lane byte offset of column chunk q.  A column right of the active extent holds exactly zero (and was never written):
+    // its lane offset lies beyond the buffer's range, where a buffer load returns 0 by itself -- no select per load
+    int xo[Q];
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         const int xi = d_clamp(x0 - m - G + lane + 64 * q, 0, Pw - 1);
-        xz[q] = xi >= ex;
-        xo[q] = min(xi, ex - 1) * 4;
+        xo[q] = xi >= ex ? (int)0x80000000 : xi * 4;
     }
     auto issue = [&](int ch) {
 #pragma unroll
         for (int k = 0; k < RW; k++) {
             const int soff = (PL_V + ch) * plane4 + min(y0 + w + NW * k, Ph - 1) * g.pitch * 4;
 #pragma unroll
-            for (int q = 0; q < Q; q++) {
+            for (int q = 0; q < Q; q++)
                 v[k][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wrsrc, xo[q], soff, 0));
-                if (xz[q]) v[k][q] = 0.f;
-            }
         }
     };
     auto commit = [&]() {
@@ -850,12 +848,15 @@ constexpr int BV_R = 14, BV_NW = 4;   // fb_blur_v: 64 columns x (NW*R) = 56 row
 constexpr int BVS_NW = 8;             // fb_blur_v_stream: chunks of 8 x 14 = 112 rows, ring of 214 + 22 rows = 60 KB, 2 blocks / CU
                                       // (measured per launch: 4 waves 1.55 ms, 6 waves 1.70, 8 waves 1.53, 16 waves 1.84; tiled form 1.67)
 #ifndef MA_BH_ROWS
-#define MA_BH_ROWS 64
+#define MA_BH_ROWS 32
 #endif
-constexpr int BH_ROWS = MA_BH_ROWS;   // rows per block of fb_blur_h_solve (64, or 32: half-wave rows)
+constexpr int BH_ROWS = MA_BH_ROWS;   // rows per block of fb_blur_h_solve: 32 (half-wave rows, 4 waves) or 64 (8 waves)
 constexpr int BH_R = 14, BH_NW = 8 * BH_ROWS / 64;
-                                      // fb_blur_h_solve: 64 rows x 112 columns per block (56 KB tile, 2 blocks / CU, 4 waves / SIMD at
-                                      // ~124 VGPRs; measured per launch: R 8 x 8 waves 2.142 ms, R 14 x 4 waves 2.227, R 14 x 8 waves 2.104)
+                                      // fb_blur_h_solve: 112 columns per block either way, 4 waves / SIMD at ~126 VGPRs.  Round 5: 32 rows x 4
+                                      // waves (29 KB, FOUR blocks / CU) instead of 64 rows x 8 waves (58 KB, two): the SIMDs issue a VALU
+                                      // instruction in 85 % (non-last) / 87 % (last) of their cycles instead of 73 % / 79 %
+                                      // (profiles/r05_sq_counters_cfg3.txt), 30.1 -> 27.9 ms per step.  Earlier, per launch: R 8 x 8 waves
+                                      // 2.142 ms, R 14 x 4 waves x 64 rows (2.8 x staging) 2.227, R 14 x 8 waves 2.104
 constexpr int BH_TXW = BH_NW * BH_R * (64 / BH_ROWS);
 constexpr size_t LDS_MAX = 160 * 1024;
 

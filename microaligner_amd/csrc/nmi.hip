@@ -5,6 +5,7 @@
 #include "ma_internal.h"
 
 #include <cfloat>
+#include <cstdlib>
 
 namespace {
 
@@ -20,21 +21,33 @@ namespace {
 constexpr int HIST_SLICE16 = 65520;
 // blockIdx.z selects the second label image (b0 or b1: the "after" and the "before" half of the gate share `a` and one
 // launch); its histograms follow those of b0.
-template <int NT>
+// NB > 1: the labels of `a` are cut into NB bands and a block counts one band of its slice (blockIdx.z = image * NB + band):
+// 128 / NB KiB of LDS instead of 128 -- the form for the coarse pyramid levels, whose gate runs while the companion stream's
+// dog() blocks hold 141 of every CU's 160 KiB of LDS: a 128 KiB block is not placed before BOTH resident dog() blocks of a
+// CU have gone, and other dog() blocks keep taking the half that frees up first (13 us alone, 1140 us beside the companion's
+// full-resolution dog(): profiles/r05_notes.md -- the step time does not change, the wait is the companion's progress, but the
+// gate no longer queues behind it).  The slice is read NB times (from L2: these levels are a few MB).
+template <int NT, int NB>
 __global__ __launch_bounds__(NT) void joint_hist16_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b0,
                                                           const uint8_t* __restrict__ b1, size_t n, size_t chunk,
                                                           unsigned* __restrict__ hist)
 {
-    extern __shared__ unsigned h[];              // [256 * 256 / 2]
-    const uint8_t* __restrict__ b = blockIdx.z ? b1 : b0;
+    extern __shared__ unsigned h[];              // [256 * 256 / 2 / NB]
+    constexpr int WORDS = 32768 / NB, BAND = 256 / NB;
+    const unsigned img = blockIdx.z / NB, band = blockIdx.z % NB;
+    const uint8_t* __restrict__ b = img ? b1 : b0;
     const size_t c0 = (size_t)blockIdx.y * chunk;
     const size_t c1 = c0 + chunk < n ? c0 + chunk : n;
     size_t s0 = c0 + (size_t)blockIdx.x * HIST_SLICE16;
     const size_t s1 = s0 + HIST_SLICE16 < c1 ? s0 + HIST_SLICE16 : c1;
     if (s0 >= s1) return;
-    for (int i = threadIdx.x; i < 32768; i += NT) h[i] = 0;
+    for (int i = threadIdx.x; i < WORDS; i += NT) h[i] = 0;
     __syncthreads();
     auto count = [&](unsigned ai, unsigned bi) {
+        if (NB > 1) {
+            ai -= band * BAND;
+            if (ai >= (unsigned)BAND) return;
+        }
         const unsigned bin = ai * 256u + bi;
         atomicAdd(&h[bin >> 1], 1u << ((bin & 1u) * 16u));
     };
@@ -54,8 +67,8 @@ __global__ __launch_bounds__(NT) void joint_hist16_kernel(const uint8_t* __restr
     }
     for (size_t i = al + nvec * 16 + threadIdx.x; i < s1; i += NT) count(a[i], b[i]);
     __syncthreads();
-    unsigned* hh = hist + ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * 65536;
-    for (int i = threadIdx.x; i < 32768; i += NT) {
+    unsigned* hh = hist + ((size_t)img * gridDim.y + blockIdx.y) * 65536 + (size_t)band * (2 * WORDS);
+    for (int i = threadIdx.x; i < WORDS; i += NT) {
         const unsigned c = h[i];
         if (c & 0xffffu) atomicAdd(&hh[2 * i], c & 0xffffu);
         if (c >> 16) atomicAdd(&hh[2 * i + 1], c >> 16);
@@ -185,8 +198,15 @@ int ma_nmi_u8_enqueue2(ma_ctx* ctx, const uint8_t* a, const uint8_t* b0, const u
         MA_HIP(hipMemsetAsync(hist, 0, hist_bytes, ctx->stream));
         const size_t slices = (chunk + HIST_SLICE16 - 1) / HIST_SLICE16;
         MA_REQUIRE(slices <= 0x7fffffff, "chunk too large");
-        hipLaunchKernelGGL((joint_hist16_kernel<1024>), dim3((unsigned)slices, (unsigned)nchunks, nimg), dim3(1024),
-                           32768 * sizeof(unsigned), ctx->stream, a, b0, b1, n, chunk, hist);
+        // small inputs (the coarse pyramid levels: up to 2048^2 per image) in eight label bands of 16 KiB of LDS each
+        constexpr int NB = 8;
+        static const size_t band_max = [] { const char* e = getenv("MICROALIGNER_NMI_BAND_MAX_PX"); return e ? (size_t)atoll(e) : (size_t)1 << 22; }();
+        if (n <= band_max && (size_t)nimg * NB <= 65535)
+            hipLaunchKernelGGL((joint_hist16_kernel<1024, NB>), dim3((unsigned)slices, (unsigned)nchunks, nimg * NB), dim3(1024),
+                               32768 / NB * sizeof(unsigned), ctx->stream, a, b0, b1, n, chunk, hist);
+        else
+            hipLaunchKernelGGL((joint_hist16_kernel<1024, 1>), dim3((unsigned)slices, (unsigned)nchunks, nimg), dim3(1024),
+                               32768 * sizeof(unsigned), ctx->stream, a, b0, b1, n, chunk, hist);
         hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)(nimg * nchunks)), dim3(NR_T), 0, ctx->stream, hist, n, chunk,
                            (unsigned)nchunks, scores);
         MA_HIP(hipGetLastError());

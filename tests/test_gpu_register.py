@@ -858,3 +858,34 @@ def test_register_random_configurations_match_the_oracle(seed):
     w.tile_size, w.overlap = tile, overlap
     w.image, w.flow = mov, flow
     assert np.array_equal(w.warp(), RO.warp(mov, exp_flow, tile, overlap)), params
+
+
+def test_results_land_by_dma_in_caller_memory_that_was_page_locked_in_place(ctx, tmp_path):
+    """ma_host_register (device.host_register, parallel.shared_array): a caller-owned array -- here an np.empty and a
+    shared-memory .npy memmap like the ones a multi-rank run writes its results into -- is page-locked in place; downloads
+    into it and uploads from it go by DMA directly (the staging rings stay untouched: nothing is counted twice, the bytes are
+    right), and the registration ends with the array."""
+    from microaligner_amd import device, parallel
+    rng = np.random.default_rng(8)
+    src = rng.random((2048, 3000)).astype(np.float32)            # 24.6 MB: above the staging threshold
+    dev = ctx.asdevice(src)
+    plain = np.empty_like(src)
+    assert device.host_register(plain) is True
+    dev.numpy(out=plain)
+    assert np.array_equal(plain, src)
+    back = ctx.asdevice(plain.copy()).numpy()
+    assert np.array_equal(back, src)
+    # a node-wide result array: one rank here, the mapping is page-locked where a device exists
+    name = f"ma_test_{os.getpid()}.npy"
+    shared = parallel.shared_array(name, (2,) + src.shape, np.float32, directory="/dev/shm", unlink=True)
+    assert parallel.arr_is_page_locked(shared)
+    dev.numpy(out=shared[1])
+    assert np.array_equal(shared[1], src) and not shared[0].any()
+    # upload FROM page-locked caller memory
+    shared[0][...] = src[::-1]
+    assert np.array_equal(ctx.asdevice(shared[0]).numpy(), src[::-1])
+    del shared, plain
+    import gc
+    gc.collect()
+    # memory that cannot be registered is reported, not raised
+    assert device.host_register(np.empty(0, np.float32)) is False
