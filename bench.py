@@ -224,13 +224,40 @@ def cpu_model():
     return "unknown"
 
 
+def effective_cpus():
+    """(CPUs this process can actually run on at once, how that was found): the smaller of the scheduler's affinity mask and
+    the container's CPU-time quota (cgroup v2 cpu.max / v1 cfs_quota).  The GPU boxes of this pool show 256 hardware threads
+    and grant 16 CPUs of time (cpu.max 1600000 100000): 256 worker threads there are 16 cores' worth of work, throttled."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    how = "affinity"
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, how = max(1, int(quota)), f"cgroup CPU quota ({quota:g} of {os.cpu_count()} hardware threads)"
+    return n, how
+
+
 def cpu_baseline_opencv(sample, params):
     """BASELINE.md section 2, plan A: the reference's orchestration over a LIVE cv2 (oracle/cv2_backend.py: the cv2 calls
     as the reference writes them, Farneback windows and NMI chunks fanned out over one worker per hardware thread the way
     utils.py:117-119 / flow_calc.py:93-97 fan them out over dask processes).  Raises ImportError where no cv2 imports."""
     from microaligner_amd import synthetic
     from oracle import cv2_backend
-    cores = os.cpu_count() or 1
+    cores, cores_how = effective_cpus()
     ref, mov = synthetic.make_pair(sample, sample, 1)
     stages = {}
     t0 = time.perf_counter()
@@ -238,7 +265,7 @@ def cpu_baseline_opencv(sample, params):
     dt = time.perf_counter() - t0
     info = cv2_backend.build_summary()
     return {"value": round(sample * sample / dt / 1e6, 3), "unit": "Mpix/s", "cores": cores,
-            "kind": "port" if info["standin"] else "opencv", "cpu": cpu_model(), "opencv": info,
+            "kind": "port" if info["standin"] else "opencv", "cpu": cpu_model(), "cores_limit": cores_how, "opencv": info,
             "stage_seconds": {k: round(v, 2) for k, v in stages.items()},
             "sample": f"{sample}x{sample} f32 pair, same parameters as the GPU workload, register()+warp(), {dt:.1f} s wall; "
                       f"cv2 {info['version']} called as the reference calls it, {cores} windows / NMI chunks in flight "
@@ -257,7 +284,7 @@ def cpu_baseline(sample, params):
         pass
     from microaligner_amd import synthetic
     from oracle import register_oracle as RO
-    cores = os.cpu_count() or 1
+    cores, cores_how = effective_cpus()
     ref, mov = synthetic.make_pair(sample, sample, 1)
     stages = {}
     t0 = time.perf_counter()
@@ -269,7 +296,7 @@ def cpu_baseline(sample, params):
     dt = t1 - t0
     nwin = (-(-sample // params.get("tile_size", 1000))) ** 2
     return {"value": round(sample * sample / dt / 1e6, 3), "unit": "Mpix/s", "cores": cores, "kind": "port",
-            "cpu": cpu_model(), "stage_seconds": {k: round(v, 2) for k, v in stages.items()},
+            "cpu": cpu_model(), "cores_limit": cores_how, "stage_seconds": {k: round(v, 2) for k, v in stages.items()},
             "sample": f"{sample}x{sample} f32 pair, same parameters as the GPU workload, register()+warp(), "
                       f"{dt:.1f} s wall; C restatement of the OpenCV / scikit-learn arithmetic (no cv2 in the image) "
                       f"with {cores} OpenMP threads: the Farneback windows of a level ({nwin} at full resolution, one "
@@ -932,7 +959,9 @@ def main():
                 informational(V, f"lanes{args.lanes}", leg_lanes)
         if world == 1 and not args.no_cpu_baseline and not args.pairs_total:
             set_affinity(all_cpus)      # the CPU baseline uses every core of the host, not just the GPU's node
-            sample = args.cpu_sample or (H if (os.cpu_count() or 1) >= 128 else 4096)
+            # a bounded sample: the full workload where >= 128 CPUs can really run, else 4096^2 (the GPU boxes of this pool grant
+            # 16 CPUs of time: the full 16384^2 pair would take minutes there)
+            sample = args.cpu_sample or (H if effective_cpus()[0] >= 128 else 4096)
             informational(res, "cpu_baseline", lambda: cpu_baseline(min(sample, H), params))
         for key, name in (("roofline_blur_v", "blur_v"), ("roofline_polyexp", "polyexp_m0")):
             if name != dominant:

@@ -632,14 +632,20 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
     } else {
         auto epilogue = [&](auto near_border_tag) {
             constexpr bool NEAR_BORDER = decltype(near_border_tag)::value;
-            for (int p = tid; p < ROWS * TXW; p += NT) {
-                const int rh = p / TXW, c = p - rh * TXW;
+            // pixel p = tid + k * NT of the tile, row-major: (row, column) and the byte offset of the pixel advance by
+            // constants (NT = DR rows + DC columns; one more row when the column wraps) -- no division, no multiply
+            constexpr int DR = NT / TXW, DC = NT % TXW;
+            const int pitch4 = g.pitch * 4;
+            int rh = tid / TXW, c = tid - rh * TXW;
+            int pix4 = ((y0 + rh) * g.pitch + x0 + c) * 4;
+            int tbi = rh * TP + c;            // index of the pixel's flow in the LDS tile
+            for (int p = tid; p < ROWS * TXW; p += NT, rh += DR, c += DC, pix4 += DR * pitch4 + DC * 4, tbi += DR * TP + DC) {
+                if (c >= TXW) { c -= TXW; rh += 1; pix4 += pitch4 - TXW * 4; tbi += TP - TXW; }
                 const int y = y0 + rh, x = x0 + c;
                 if (y < yend && x >= need.x0 && x < xend) {
-                    const ma_f2 f = tb[rh * TP + c];
+                    const ma_f2 f = tb[tbi];
                     const float dx = f.x, dy = f.y;
                     // UpdateMatrices (A.1 step 3) at this pixel
-                    const int pix4 = (y * g.pitch + x) * 4;
                     float r0[5];
 #pragma unroll
                     for (int k = 0; k < 5; k++)
@@ -654,7 +660,8 @@ __global__ __launch_bounds__(64 * NW, BH_WAVES) void fb_blur_h_solve(FbGeom g, i
                     if (inside && !r1zero) {
                         float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy,
                               a11 = fx * fy;
-                        const int q0 = (y1 * g.pitch + x1) * 4, q1 = q0 + g.pitch * 4;
+                        // 0 <= y1 < Ph < 2^15 and pitch < 2^16 here: a 24-bit multiply-add (full rate) serves
+                        const int q0 = (int)(__umul24((unsigned)y1, (unsigned)g.pitch) + (unsigned)x1) * 4, q1 = q0 + pitch4;
 #pragma unroll
                         for (int k = 0; k < 5; k++) {
                             const int so = (PL_R1 + k) * plane4;

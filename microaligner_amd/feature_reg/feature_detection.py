@@ -115,10 +115,21 @@ def match_features(img1_features: Features, img2_features: Features, verbose: bo
     return identity if mat is None else mat
 
 
+_DAISY_TABLES = {}
+
+
 def _daisy_tables(daisy: Daisy):
     """Host-side constants of the device DAISY (ma_daisy_describe): the centre-first halves of scipy's Gaussian
     kernels for the three smoothing increments (truncate 3.0), the (cos, sin) of the orientation bins and the
-    sampling offsets -- the very doubles sparse_cpu.Daisy uses."""
+    sampling offsets -- the very doubles sparse_cpu.Daisy uses.  Computed once per parameter set (a register() asks
+    for them twelve times)."""
+    key = (daisy.radius, daisy.q_radius, daisy.q_theta, daisy.q_hist)
+    if key not in _DAISY_TABLES:
+        _DAISY_TABLES[key] = _daisy_tables_uncached(daisy)
+    return _DAISY_TABLES[key]
+
+
+def _daisy_tables_uncached(daisy: Daisy):
     from scipy.ndimage._filters import _gaussian_kernel1d
     halves = []
     for inc in daisy.smoothing_increments():

@@ -259,17 +259,24 @@ def estimate_affine_partial_2d(src_pts: np.ndarray, dst_pts: np.ndarray, confide
     rng = np.random.default_rng(seed)
     best_mask, best_count, iters, it = None, 0, max_iters, 0
     thr2 = reproj_threshold * reproj_threshold
+    sx, sy, dx, dy = (np.ascontiguousarray(v) for v in (src[:, 0], src[:, 1], dst[:, 0], dst[:, 1]))
     while it < iters:
         it += 1
         i, j = rng.choice(n, 2, replace=False)
-        if np.allclose(src[i], src[j]):
+        # np.allclose(src[i], src[j]) spelled out (its call overhead was a third of a RANSAC round)
+        if (abs(sx[i] - sx[j]) <= 1e-8 + 1e-5 * abs(sx[j])) and (abs(sy[i] - sy[j]) <= 1e-8 + 1e-5 * abs(sy[j])):
             continue
-        M = _fit_similarity(src[[i, j]], dst[[i, j]])
-        if M is None:
+        # the similarity through two point pairs in closed form: z = (q1 - q0) / (p1 - p0) as complex numbers, t = q0 - z p0
+        # (the least-squares solve of the same 4 x 4 system took 0.14 ms per sample in numpy)
+        ux, uy, vx, vy = sx[j] - sx[i], sy[j] - sy[i], dx[j] - dx[i], dy[j] - dy[i]
+        den = ux * ux + uy * uy
+        if den == 0.0:
             continue
-        err = ((src @ M[:, :2].T + M[:, 2] - dst) ** 2).sum(1)
-        mask = err < thr2
-        count = int(mask.sum())
+        a, b = (vx * ux + vy * uy) / den, (vy * ux - vx * uy) / den
+        tx, ty = dx[i] - (a * sx[i] - b * sy[i]), dy[i] - (b * sx[i] + a * sy[i])
+        ex, ey = a * sx - b * sy + tx - dx, b * sx + a * sy + ty - dy
+        mask = ex * ex + ey * ey < thr2
+        count = int(np.count_nonzero(mask))
         if count > best_count:
             best_count, best_mask = count, mask
             w = count / n
