@@ -959,9 +959,9 @@ def main():
                 informational(V, f"lanes{args.lanes}", leg_lanes)
         if world == 1 and not args.no_cpu_baseline and not args.pairs_total:
             set_affinity(all_cpus)      # the CPU baseline uses every core of the host, not just the GPU's node
-            # a bounded sample: the full workload where >= 128 CPUs can really run, else 4096^2 (the GPU boxes of this pool grant
-            # 16 CPUs of time: the full 16384^2 pair would take minutes there)
-            sample = args.cpu_sample or (H if effective_cpus()[0] >= 128 else 4096)
+            # a bounded sample: the full workload where >= 128 CPUs can really run, else 8192^2 (the GPU boxes of this pool grant
+            # 16 CPUs of time: ~9 s there; the full 16384^2 pair would take most of a minute)
+            sample = args.cpu_sample or (H if effective_cpus()[0] >= 128 else 8192)
             informational(res, "cpu_baseline", lambda: cpu_baseline(min(sample, H), params))
         for key, name in (("roofline_blur_v", "blur_v"), ("roofline_polyexp", "polyexp_m0")):
             if name != dominant:
