@@ -1,4 +1,5 @@
 """Host-side logic that needs no GPU: API surface, validation, tile geometry, synthetic inputs."""
+import os
 import numpy as np
 import pytest
 
@@ -503,3 +504,24 @@ def test_warper_routes_large_host_pages_through_the_page_driver(monkeypatch):
         run(np.ones((4, 4, 3), np.uint8), np.zeros((4, 4, 2), np.float32))
     with pytest.raises(ValueError):
         run(np.array([]), flow_small)
+
+
+def test_bench_counts_the_cpus_the_container_grants(tmp_path, monkeypatch):
+    """bench.effective_cpus(): the smaller of the affinity mask and the cgroup CPU-time quota -- the GPU boxes of this pool show
+    256 hardware threads and grant 16 CPUs of time, and `cpu_baseline.cores` must say 16."""
+    import builtins
+    import bench
+    n, how = bench.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1) and how
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == "/sys/fs/cgroup/cpu.max":
+            p = tmp_path / "cpu.max"
+            p.write_text("200000 100000\n")
+            return real_open(p, *a, **k)
+        return real_open(path, *a, **k)
+    monkeypatch.setattr(builtins, "open", fake_open)
+    if len(os.sched_getaffinity(0)) > 2:
+        n, how = bench.effective_cpus()
+        assert n == 2 and "quota" in how
