@@ -961,6 +961,8 @@ def host_register(arr):
     while isinstance(getattr(base, "base", None), np.ndarray):     # the finalizer hangs on the object that owns the memory
         base = base.base
     try:
+        # (the finalizer must run BEFORE the memory is unmapped: it hangs on the owning ndarray / memmap, whose death precedes
+        # the release of its buffer)
         weakref.finalize(base, lib.ma_host_unregister, C.c_void_p(ptr))
     except TypeError:                                                # not weak-referenceable: stays registered
         pass

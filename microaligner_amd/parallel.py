@@ -102,7 +102,7 @@ def _run_local(units: Sequence, mine: List[int], fn: Callable, lanes: int):
     return results
 
 
-def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: bool = False, page_locked: bool = True):
+def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: bool = False, page_locked=True):
     """A node-wide array every rank maps: rank 0 creates `directory/name` (POSIX shared memory by default; any path
     works, e.g. next to the output TIFF), the others open it after a barrier.  COLLECTIVE (every rank calls it with
     the same arguments).  This is where results of a sharded run go instead of being pickled through the control plane:
@@ -111,11 +111,13 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: b
     unlink=True: the name is removed as soon as every rank has mapped the file -- the mappings stay valid, the memory goes
     back when the last rank drops its array or dies, and nothing is left behind in /dev/shm whatever happens later (use it
     for scratch results; keep the name, and remove it with shared_array_unlink, when another process is to open it).
-    page_locked=True: every rank page-locks ITS mapping in place (device.host_register) when it has a HIP device, so that
-    its download engine writes results by DMA straight into the shared memory -- no staging copy: per result byte one
-    pass over host DRAM instead of three, which is what keeps eight ranks within the host's memory bandwidth (DESIGN.md
-    section 6).  Where the runtime refuses (no device: gloo tests, --dry-run; a file on disk) the array is pageable as before;
-    `arr_is_page_locked(arr)` tells."""
+    page_locked=True: every rank page-locks, in ITS mapping, the rows of the leading axis that `shard()` deals to it (rank,
+    rank + world, ...: the rows it will write; pinning the whole array in every rank would pin every page world-size
+    times over) when it has a HIP device (device.host_register), so that its download engine writes results by DMA straight
+    into the shared memory -- no staging copy: per result byte one pass over host DRAM instead of three, which is what keeps
+    eight ranks within the host's memory bandwidth.  page_locked="all": the whole array (a rank that
+    writes rows of its own choosing).  Where the runtime refuses (no device: gloo tests, --dry-run; a file on disk) the
+    array is pageable as before; `arr_is_page_locked(arr)` tells."""
     import numpy as np
     rank, ws = world()
     # SINGLE NODE: the file is created once and every rank maps that one file.  A launch that spans nodes has ranks whose
@@ -137,21 +139,24 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: b
         _barrier()
         if rank == 0:
             os.unlink(path)
-    if page_locked:
-        _page_lock(arr)
+    if page_locked == "all" or (page_locked and (ws == 1 or arr.ndim < 2)):
+        _page_lock(arr, [arr])
+    elif page_locked:
+        _page_lock(arr, [arr[i] for i in range(rank, arr.shape[0], ws)])
     return arr
 
 
 _PAGE_LOCKED = {}      # id(memmap) -> True, dropped with the array
 
 
-def _page_lock(arr):
-    """Best effort: only where a device exists in this process (the registration needs the HIP runtime)."""
+def _page_lock(arr, pieces):
+    """Best effort: only where a device exists in this process (the registration needs the HIP runtime).  pieces: views of
+    `arr` (contiguous blocks) to register; the registrations end with `arr` (the views' finalizers hang on its buffer)."""
     try:
         from . import device
-        if device.device_count() <= 0:
+        if device.device_count() <= 0 or not pieces:
             return False
-        ok = device.host_register(arr)
+        ok = all([device.host_register(p) for p in pieces])
     except Exception:   # noqa: BLE001 -- no library / no device: the staging path serves the array
         return False
     if ok:
