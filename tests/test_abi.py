@@ -108,6 +108,40 @@ def test_host_copy_pool_copies_every_byte(fn):
     assert copy(None, None, 8) == _lib.MA_EINVAL
 
 
+def test_host_copy_pool_survives_a_fork():
+    """A fork()ed child (multiprocessing's fork start method, dask workers) inherits the pool object but none of its worker
+    threads: a copy of a few MiB must not wait for them (it used to wait forever).  The parent's pool keeps working."""
+    import multiprocessing as mp
+    from microaligner_amd import _lib
+    lib = _lib.load()
+    src = np.arange(6 << 20, dtype=np.uint8)
+    dst = np.zeros_like(src)
+    _lib.check(lib.ma_host_parallel_copy(dst.ctypes.data, src.ctypes.data, src.nbytes))      # the pool's threads exist now
+    assert np.array_equal(dst, src)
+
+    def child(q):
+        d = np.zeros_like(src)
+        rc1 = lib.ma_host_parallel_copy(d.ctypes.data, src.ctypes.data, src.nbytes)
+        ok1 = bool(np.array_equal(d, src))
+        d[:] = 0
+        rc2 = lib.ma_host_stream_copy(d.ctypes.data, src.ctypes.data, src.nbytes)
+        q.put((rc1, ok1, rc2, bool(np.array_equal(d, src))))
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=child, args=(q,))
+    p.start()
+    p.join(60)
+    alive = p.is_alive()
+    if alive:
+        p.kill()
+    assert not alive, "the forked child hung in the copy pool"
+    assert q.get(timeout=10) == (0, True, 0, True)
+    dst[:] = 0
+    _lib.check(lib.ma_host_parallel_copy(dst.ctypes.data, src.ctypes.data, src.nbytes))
+    assert np.array_equal(dst, src)
+
+
 def test_register_entry_rejects_bad_parameters_without_a_device():
     from microaligner_amd import _lib
     lib = _lib.load()
