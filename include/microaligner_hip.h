@@ -315,6 +315,10 @@ int ma_dog_u8(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sig
  * ceil(n/chunk) scores to scores_host (caller takes the mean). */
 int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t chunk,
               double* scores_host, int max_scores, int* n_scores);
+/* mutual_information_test (similarity_scoring.py:52-58): both halves of the gate -- NMI(a, b0) and NMI(a, b1) -- share the
+ * reference labels `a`, one pair of launches and one synchronisation. */
+int ma_nmi_u8_pair(ma_ctx* ctx, const uint8_t* a, const uint8_t* b0, const uint8_t* b1, size_t n, size_t chunk,
+                   double* scores0_host, double* scores1_host, int max_scores, int* n_scores);
 
 /* ---- "next" rows ------------------------------------------------
  * np.maximum fold over z-planes (utils.py:92) and

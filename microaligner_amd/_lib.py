@@ -63,6 +63,7 @@ SIGNATURES = {
     "ma_minmax": (_i, [_vp, _vp, _i, _sz, C.POINTER(_d), C.POINTER(_d)]),
     "ma_dog_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(_i)]),
     "ma_nmi_u8": (_i, [_vp, _vp, _vp, _sz, _sz, C.POINTER(_d), _i, C.POINTER(_i)]),
+    "ma_nmi_u8_pair": (_i, [_vp, _vp, _vp, _vp, _sz, _sz, C.POINTER(_d), C.POINTER(_d), _i, C.POINTER(_i)]),
     "ma_max_project": (_i, [_vp, _vp, _i, _i, _sz, _vp]),
     "ma_normalize_minmax_u8": (_i, [_vp, _vp, _i, _sz, _vp]),
     "ma_warp_affine": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _vp]),

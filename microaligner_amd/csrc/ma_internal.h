@@ -131,8 +131,6 @@ int ma_nmi_u8_enqueue2(ma_ctx* ctx, const uint8_t* a, const uint8_t* b0, const u
                        double* scores0_pinned_host, double* scores1_pinned_host, int max_scores, int* n_scores);
 
 int ma_ws_reserve(ma_ctx* ctx, size_t bytes);      // ensures ctx->ws has >= bytes
-// cv2.pyrDown that also leaves (min, max) of its SOURCE image on the device (pyramid.hip)
-int ma_pyr_down_srcminmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst, float* src_minmax_dev);
 // workspace one dog() call of an (h, w) image takes from ctx->ws (dog.hip)
 size_t ma_dog_workspace_bytes(int h, int w, int low_sigma);
 int ma_pinned_reserve(ma_ctx* ctx, size_t bytes);

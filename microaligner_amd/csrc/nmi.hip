@@ -240,4 +240,20 @@ int ma_nmi_u8(ma_ctx* ctx, const uint8_t* a, const uint8_t* b, size_t n, size_t 
     return MA_OK;
 }
 
+int ma_nmi_u8_pair(ma_ctx* ctx, const uint8_t* a, const uint8_t* b0, const uint8_t* b1, size_t n, size_t chunk,
+                   double* scores0_host, double* scores1_host, int max_scores, int* n_scores)
+{
+    MA_REQUIRE(ctx && b1 && scores0_host && scores1_host && n_scores, "NULL argument");
+    const size_t nchunks = (chunk == 0 || chunk >= n || n == 0) ? 1 : (n + chunk - 1) / chunk;
+    MA_REQUIRE(nchunks <= 65535 && (size_t)max_scores >= nchunks, "scores buffer too small");
+    MA_TRY(ma_pinned_reserve(ctx, 2 * nchunks * sizeof(double)));
+    double* p0 = (double*)ctx->pinned;
+    double* p1 = p0 + nchunks;
+    MA_TRY(ma_nmi_u8_enqueue2(ctx, a, b0, b1, n, chunk, p0, p1, max_scores, n_scores));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->profile) MA_TRY(ma_profile_flush(ctx));
+    for (int i = 0; i < *n_scores; i++) { scores0_host[i] = p0[i]; scores1_host[i] = p1[i]; }
+    return MA_OK;
+}
+
 } // extern "C"

@@ -44,15 +44,11 @@ __device__ __forceinline__ T pyr_down_px(const T* __restrict__ src, int h, int w
 // aligned).  Pairs that touch the left/right border and everything when !vec take the per-pixel path.
 // PD_ROWS destination rows per thread: their 2*PD_ROWS + 3 source rows are loaded once (all loads issued up front).
 // MM: also reduce (min, max) of the block's outputs into part[2 * block] (see warp_tiled_kernel).
-// SRCMM: (min, max) of the SOURCE pixels the block owns instead -- destination pixel (x, y) owns source pixels
-// (2x .. 2x+1, 2y .. 2y+1), which the thread has loaded anyway: the dog() of the full-resolution image then needs no pass of
-// its own over it for cv2.normalize's minimum and maximum (register.hip).
 constexpr int PD_ROWS = 4;
-template <typename T, bool MM, bool SRCMM = false>
+template <typename T, bool MM>
 __global__ __launch_bounds__(256) void pyr_down_kernel(const T* __restrict__ src, int h, int w, T* __restrict__ dst,
                                                        int dh, int dw, int vec, float* __restrict__ part)
 {
-    static_assert(!(MM && SRCMM), "one reduction per launch");
     using A = typename PyrAcc<T>::type;
     using V2 = typename PyrVec<T>::v2;
     using V4 = typename PyrVec<T>::v4;
@@ -64,17 +60,12 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const T* __restrict__ src
         *at = v;
         if (MM) { lo = fminf(lo, (float)v); hi = fmaxf(hi, (float)v); }
     };
-    auto see = [&](T v) { lo = fminf(lo, (float)v); hi = fmaxf(hi, (float)v); };
     if (x0 < dw) {
         if (!vec || p == 0 || 4 * p + 4 >= w || x0 + 1 >= dw) {
             for (int r = 0; r < PD_ROWS && y0 + r < dh; r++) {
                 T* drow = dst + (size_t)(y0 + r) * dw;
                 put(drow + x0, pyr_down_px<T>(src, h, w, x0, y0 + r));
                 if (x0 + 1 < dw) put(drow + x0 + 1, pyr_down_px<T>(src, h, w, x0 + 1, y0 + r));
-            }
-            if (SRCMM) {   // border threads: the owned source pixels once more, clipped to the image
-                for (int yy = 2 * y0; yy < min(2 * (y0 + PD_ROWS), h); yy++)
-                    for (int xx = 4 * p; xx < min(4 * p + 4, w); xx++) see(src[(size_t)yy * w + xx]);
             }
         } else {
             V2 l[NR];
@@ -87,11 +78,6 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const T* __restrict__ src
                 l[k] = *reinterpret_cast<const V2*>(s - 2);
                 m[k] = *reinterpret_cast<const V4*>(s);
                 e[k] = s[4];
-            }
-            if (SRCMM) {   // source rows 2 y0 .. 2 y0 + 7 are k = 2 .. 9; columns 4p .. 4p + 3 are m[k]
-#pragma unroll
-                for (int k = 2; k < NR - 1; k++)
-                    if (2 * y0 + k - 2 < h) { see(m[k].x); see(m[k].y); see(m[k].z); see(m[k].w); }
             }
             A ra[NR], rb[NR];
 #pragma unroll
@@ -115,7 +101,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const T* __restrict__ src
             }
         }
     }
-    if (MM || SRCMM) d_block_minmax(lo, hi, part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
+    if (MM) d_block_minmax(lo, hi, part + 2 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x));
 }
 
 // horizontally upsampled value of one source row at destination column X (two channels)
@@ -212,8 +198,7 @@ __global__ __launch_bounds__(256) void pyr_up_flow_kernel(const float2* __restri
 
 extern "C" {
 
-static int pyr_down_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst, float* minmax_dev,
-                         bool of_source = false)
+static int pyr_down_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst, float* minmax_dev)
 {
     MA_REQUIRE(ctx && src && dst, "NULL argument");
     MA_REQUIRE(dtype == MA_U8 || dtype == MA_U16 || dtype == MA_F32, "dtype must be u8/u16/f32");
@@ -230,8 +215,7 @@ static int pyr_down_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, 
     }
     MaProfScope ps(ctx, MA_K_PYR_DOWN, (double)h * w);
     const int vec = (w % 4 == 0) && ((size_t)src % 16 == 0) && ((size_t)dst % 8 == 0);
-#define MA_PD(T) do { if (part && of_source) hipLaunchKernelGGL((pyr_down_kernel<T, false, true>), grid, block, 0, ctx->stream, (const T*)src, h, w, (T*)dst, dh, dw, vec, part); \
-                      else if (part) hipLaunchKernelGGL((pyr_down_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)src, h, w, (T*)dst, dh, dw, vec, part); \
+#define MA_PD(T) do { if (part) hipLaunchKernelGGL((pyr_down_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)src, h, w, (T*)dst, dh, dw, vec, part); \
                       else hipLaunchKernelGGL((pyr_down_kernel<T, false>), grid, block, 0, ctx->stream, (const T*)src, h, w, (T*)dst, dh, dw, vec, part); } while (0)
     if (dtype == MA_U8) MA_PD(uint8_t);
     else if (dtype == MA_U16) MA_PD(uint16_t);
@@ -241,17 +225,6 @@ static int pyr_down_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, 
     if (part) MA_TRY(ma_launch_minmax_final(ctx, part, (int)nblk, minmax_dev));
     return MA_OK;
 }
-
-} // extern "C"
-
-// cv2.pyrDown that also leaves (min, max) of its SOURCE on the device (internal: register.hip's pyramid)
-int ma_pyr_down_srcminmax(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst, float* src_minmax_dev)
-{
-    MA_REQUIRE(src_minmax_dev, "NULL argument");
-    return pyr_down_impl(ctx, src, dtype, h, w, dst, src_minmax_dev, true);
-}
-
-extern "C" {
 
 int ma_pyr_down(ma_ctx* ctx, const void* src, int dtype, int h, int w, void* dst)
 {

@@ -152,7 +152,7 @@ int merge_level(ma_ctx* ctx, Flow& f1, Flow& f2, int h, int w, int tile, int ove
     return ma_merge_flows_tiled(ctx, f1.p, f2.p, h, w, tile, overlap, out);
 }
 
-struct Level { Buf data; const void* ptr = nullptr; int h = 0, w = 0, factor = 1; Buf minmax; };   // minmax: (min, max) on the device, if a producer left it
+struct Level { Buf data; const void* ptr = nullptr; int h = 0, w = 0, factor = 1; };
 
 // _generate_img_pyr (optflow_registrator.py:175-202): smallest level first; a level is kept while both sides stay
 // >= 100 px; the full-resolution image is appended when use_full_res_img
@@ -161,9 +161,6 @@ int build_pyramid(ma_ctx* ctx, const void* full, int dtype, int H, int W, const 
     std::vector<Level> down;
     const void* cur = full;
     int ch = H, cw = W;
-    // the full-resolution image is a level of its own and dog() will want its minimum and maximum: the first pyrDown, which
-    // reads every pixel of it anyway, reduces them on the way (a pass over 1 GB less per image at 16384^2)
-    Buf full_mm;
     for (int l = 0; l < p.num_pyr_lvl; l++) {
         const int factor = 1 << (l + 1);
         if ((double)H / factor < 100. || (double)W / factor < 100.) break;
@@ -171,13 +168,7 @@ int build_pyramid(ma_ctx* ctx, const void* full, int dtype, int H, int W, const 
         L.h = (ch + 1) / 2; L.w = (cw + 1) / 2; L.factor = factor;
         L.data = Buf(ctx, (size_t)L.h * L.w * ma_esize(dtype));
         if (!L.data) return MA_ENOMEM;
-        if (l == 0 && p.use_full_res_img) {
-            full_mm = Buf(ctx, 2 * sizeof(float));
-            if (!full_mm) return MA_ENOMEM;
-            MA_TRY(ma_pyr_down_srcminmax(ctx, cur, dtype, ch, cw, L.data.p, (float*)full_mm.p));
-        } else {
-            MA_TRY(ma_pyr_down(ctx, cur, dtype, ch, cw, L.data.p));
-        }
+        MA_TRY(ma_pyr_down(ctx, cur, dtype, ch, cw, L.data.p));
         L.ptr = L.data.p;
         cur = L.ptr; ch = L.h; cw = L.w;
         down.push_back(std::move(L));
@@ -186,7 +177,6 @@ int build_pyramid(ma_ctx* ctx, const void* full, int dtype, int H, int W, const 
     if (p.use_full_res_img) {
         Level L;
         L.ptr = full; L.h = H; L.w = W; L.factor = 1;
-        L.minmax = std::move(full_mm);
         lv.push_back(std::move(L));
     }
     return MA_OK;
@@ -298,9 +288,9 @@ int ma_optflow_register(ma_ctx* ctx, const void* ref, const void* mov, int dtype
             const Level& M = mov_pyr[lvl];
             hipEvent_t e_ref = ma_ctx_sync_event(ctx, 1 + 2 * (size_t)lvl), e_raw = ma_ctx_sync_event(ctx, 2 + 2 * (size_t)lvl);
             if (!e_ref || !e_raw) return MA_EHIP;
-            MA_TRY(dog_level(ctx, R.ptr, dtype, R.h, R.w, (const float*)R.minmax.p, p.dog_flags, ref_dogs[lvl], side));
+            MA_TRY(dog_level(ctx, R.ptr, dtype, R.h, R.w, nullptr, p.dog_flags, ref_dogs[lvl], side));
             MA_HIP(hipEventRecord(e_ref, side->stream));
-            MA_TRY(dog_level(ctx, M.ptr, dtype, M.h, M.w, (const float*)M.minmax.p, p.dog_flags, raw_dogs[lvl], side));
+            MA_TRY(dog_level(ctx, M.ptr, dtype, M.h, M.w, nullptr, p.dog_flags, raw_dogs[lvl], side));
             MA_HIP(hipEventRecord(e_raw, side->stream));
         }
     }

@@ -685,6 +685,19 @@ class Context:
         self._run(self.lib.ma_nmi_u8, a.ptr, b.ptr, n, int(max(chunk, 0)), scores, nch, C.byref(got))
         return np.frombuffer(scores, dtype=np.float64, count=got.value).copy()
 
+    def nmi_scores_pair(self, a, b0, b1, chunk=0):
+        """Both halves of the gate in one call (ma_nmi_u8_pair): (scores of NMI(a, b0), scores of NMI(a, b1))."""
+        for b in (b0, b1):
+            if a.dtype != np.uint8 or b.dtype != np.uint8 or a.size != b.size:
+                raise ValueError("NMI inputs must be uint8 arrays of equal size")
+        n = a.size
+        nch = 1 if (chunk <= 0 or chunk >= n) else (n + chunk - 1) // chunk
+        s0, s1 = (C.c_double * nch)(), (C.c_double * nch)()
+        got = C.c_int()
+        self._run(self.lib.ma_nmi_u8_pair, a.ptr, b0.ptr, b1.ptr, n, int(max(chunk, 0)), s0, s1, nch, C.byref(got))
+        return (np.frombuffer(s0, dtype=np.float64, count=got.value).copy(),
+                np.frombuffer(s1, dtype=np.float64, count=got.value).copy())
+
     def max_project(self, stack):
         nz = stack.shape[0]
         out = self.empty(stack.shape[1:], stack.dtype)

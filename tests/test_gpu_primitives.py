@@ -411,3 +411,17 @@ def test_mi_tiled_host_function(ctx):
     assert check_if_higher_similarity(a, a, b, 100, verbose=False) == [True]
     z = np.zeros((260, 250), np.float32)
     assert mi_tiled(z, z, 1000) == 1.0
+
+
+@pytest.mark.parametrize("shape,tile", [((260, 250), 100), ((260, 250), 1000), ((2300, 2100), 1000)])
+def test_both_halves_of_the_gate_in_one_call(ctx, shape, tile):
+    """mutual_information_test on three device dog() outputs goes through ma_nmi_u8_pair (shared reference labels, one pair
+    of launches, one synchronisation): the very scores of two separate mi_tiled calls, which equal the oracle's."""
+    from microaligner_amd.shared_modules.similarity_scoring import mi_tiled, mutual_information_test
+    ref, mov = pair(*shape, 5)
+    other, _ = pair(*shape, 6)
+    a, b0, b1 = (ctx.asdevice(O.dog(v, True)) for v in (ref, mov, other))
+    after, before = mutual_information_test(a, b0, b1, tile)
+    assert after == mi_tiled(a, b0, tile) and before == mi_tiled(a, b1, tile)
+    assert abs(after - RO.mi_tiled(a.numpy(), b0.numpy(), tile)) < 1e-12
+    assert abs(before - RO.mi_tiled(a.numpy(), b1.numpy(), tile)) < 1e-12
