@@ -39,6 +39,7 @@ class FeatureRegistrator:
         self.use_full_res_img = False
         self.use_dog = True
         self.verbose = True      # addition: the reference prints unconditionally
+        self.compat_mov_getter = True   # the mov_img getter returns the REFERENCE image, as the reference's does; False: the moving image
         self._levels: List[_Level] = []   # reference side, coarsest first; kept for register(reuse_ref_img=True)
 
     # -- inputs ---------------------------------------------------------------------------------------------
@@ -53,7 +54,9 @@ class FeatureRegistrator:
 
     @property
     def mov_img(self):
-        return self._mov_img  # the reference's getter returns the reference image (:62-63), an obvious slip
+        # the reference's getter returns the REFERENCE image (feature_registrator.py:59-60, an obvious slip that nothing on
+        # the path reads): so does this one unless compat_mov_getter is switched off
+        return self._ref_img if self.compat_mov_getter else self._mov_img
 
     @mov_img.setter
     def mov_img(self, img):

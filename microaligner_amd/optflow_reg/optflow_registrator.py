@@ -63,8 +63,9 @@ class OptFlowRegistrator:
         # that serves the two input classes the C entry point does not model: reference and moving image of different
         # dtypes, and float images whose max() is 0 without being all zero)
         self.engine = "c"
-        # True: the mov_img GETTER returns the reference image, as the reference's does (optflow_registrator.py:73-74)
-        self.compat_mov_getter = False
+        # True (default, the reference's behaviour): the mov_img GETTER returns the REFERENCE image, as the reference's does
+        # (optflow_registrator.py:73-74, quirk Q4 -- nothing on the path reads it); False: it returns the moving image
+        self.compat_mov_getter = True
         self.level_reports: List[LevelReport] = []
         self._warper = Warper()
         self._tile_flow_calc = TileFlowCalc()
@@ -81,8 +82,8 @@ class OptFlowRegistrator:
 
     @property
     def mov_img(self):
-        # the reference's getter returns the *reference* image (optflow_registrator.py:73-74, quirk Q4); this one
-        # returns what was set unless compat_mov_getter asks for the reference's behaviour
+        # the reference's getter returns the *reference* image (optflow_registrator.py:73-74, quirk Q4): so does this one
+        # unless compat_mov_getter is switched off
         return self._ref_img if self.compat_mov_getter else self._mov_img
 
     @mov_img.setter

@@ -177,9 +177,8 @@ def test_reference_and_moving_image_of_different_dtypes(ctx, dt_ref, dt_mov, use
     assert np.array_equal(fc.calc_flow(), RO.tile_flow(ref, mov, 200, 30, 29, 2))
     assert np.array_equal(farneback(mov, ref, 0, 21, 2),
                           O.calc_optical_flow_farneback(mov.astype(np.float32), ref.astype(np.float32), 21, 2))
-    reg.compat_mov_getter = True             # Q4: the reference's mov_img getter returns the REFERENCE image
     reg.ref_img, reg.mov_img = ref, mov
-    assert reg.mov_img is ref
+    assert reg.compat_mov_getter and reg.mov_img is ref     # Q4: the reference's mov_img getter returns the REFERENCE image
     reg.compat_mov_getter = False
     assert reg.mov_img is mov
 
