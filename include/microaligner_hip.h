@@ -58,7 +58,9 @@ enum ma_farneback_flags {
  * x86-64 host with AVX2 selects at run time use fused multiply-adds (both flags). */
 enum ma_dog_flags {
     MA_DOG_FUSED_BLUR = 1, /* row filter acc = fma(x_j, k_j, acc); column filter acc = fma(a + b, k_j, acc) */
-    MA_DOG_FUSED_SCALE = 2 /* both normalize() steps: dst = fma(src, a, b) */
+    MA_DOG_FUSED_SCALE = 2, /* both normalize() steps: dst = fma(src, a, b) */
+    MA_DOG_REPORT_ASYNC = 4 /* src_max_is_zero_host is PAGE-LOCKED memory (ma_host_alloc): the flag is copied there in stream
+                               order and the call does not synchronise; valid after the next synchronisation of the ctx */
 };
 
 /* ---- library / context ------------------------------------------------- */

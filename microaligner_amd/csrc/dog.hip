@@ -591,7 +591,8 @@ int ma_minmax(ma_ctx* ctx, const void* src, int dtype, size_t n, double* mn_host
 static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, int low_sigma, int high_sigma, uint8_t* dst,
                        int* src_max_is_zero_host, const float* src_minmax_dev, int flags)
 {
-    MA_REQUIRE((flags & ~(MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE)) == 0, "unknown DOG flag");
+    MA_REQUIRE((flags & ~(MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE | MA_DOG_REPORT_ASYNC)) == 0, "unknown DOG flag");
+    MA_REQUIRE(!(flags & MA_DOG_REPORT_ASYNC) || src_max_is_zero_host, "MA_DOG_REPORT_ASYNC needs a page-locked flag word");
     const bool fblur = (flags & MA_DOG_FUSED_BLUR) != 0;
     const int fscale = (flags & MA_DOG_FUSED_SCALE) != 0;
     MA_REQUIRE(ctx && src && dst, "NULL argument");
@@ -680,7 +681,10 @@ static int dog_u8_impl(ma_ctx* ctx, const void* src, int dtype, int h, int w, in
                        (int*)nullptr);
     hipLaunchKernelGGL((scale_to_u8<float>), dim3(grid_for(n)), dim3(256), 0, ctx->stream, diff, n, 0.f, 0.f, sc, dst, fscale);
     MA_HIP(hipGetLastError());
-    if (src_max_is_zero_host) {
+    if (src_max_is_zero_host && (flags & MA_DOG_REPORT_ASYNC)) {
+        // stream ordered: the scalars live in the workspace, which later calls reuse only behind this copy
+        MA_HIP(hipMemcpyAsync(src_max_is_zero_host, &sc->src_max_is_zero, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    } else if (src_max_is_zero_host) {
         MA_TRY(ma_pinned_reserve(ctx, 64));
         MA_HIP(hipMemcpyAsync(ctx->pinned, &sc->src_max_is_zero, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         MA_HIP(hipStreamSynchronize(ctx->stream));

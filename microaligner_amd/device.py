@@ -481,6 +481,10 @@ class Context:
                 self._closed = True
             for p in live:
                 self.lib.ma_free(self.handle, p)
+            if getattr(self, "_zero_flags_ptr", None):
+                self._zero_flags = None
+                self.lib.ma_host_free(C.c_void_p(self._zero_flags_ptr))
+                self._zero_flags_ptr = None
             self.lib.ma_ctx_destroy(self.handle)
 
     def __del__(self):
@@ -668,12 +672,53 @@ class Context:
         flags: rounding model of the chain (MA_DOG_FUSED_BLUR | MA_DOG_FUSED_SCALE, include/microaligner_hip.h)."""
         h, w = img.shape
         out = self.empty((h, w), np.uint8)
+        if report_zero == "deferred":
+            # no host sync: the flag lands in a page-locked word in stream order; any_deferred_zero() reads the words
+            # handed out since its last call once the stream has been waited for (FeatureRegistrator's fast path)
+            slot = self._zero_flag_slot()
+            self._run(self.lib.ma_dog_u8_ex, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma),
+                      int(flags) | L.MA_DOG_REPORT_ASYNC, img.minmax.ptr if img.minmax is not None else None, out.ptr,
+                      C.cast(C.c_void_p(self._zero_flags_ptr + 4 * slot), C.POINTER(C.c_int)))
+            return out
         flag = C.c_int(0)
         fl = C.byref(flag) if report_zero else None
         # img.minmax: the producing kernel already reduced the image
         self._run(self.lib.ma_dog_u8_ex, img.ptr, _dt(img.dtype), h, w, int(low_sigma), int(high_sigma), int(flags),
                   img.minmax.ptr if img.minmax is not None else None, out.ptr, fl)
         return (out, bool(flag.value)) if report_zero else out
+
+    _ZERO_FLAG_SLOTS = 1024
+
+    def _zero_flag_slot(self):
+        if getattr(self, "_zero_flags_ptr", None) is None:
+            p = C.c_void_p()
+            L.check(self.lib.ma_host_alloc(4 * self._ZERO_FLAG_SLOTS, C.byref(p)))
+            self._zero_flags_ptr = p.value
+            self._zero_flags = np.frombuffer((C.c_int * self._ZERO_FLAG_SLOTS).from_address(p.value), np.int32)
+            self._zero_pending, self._zero_next, self._zero_carry = [], 0, False
+        if len(self._zero_pending) >= self._ZERO_FLAG_SLOTS and self._settle_zero_flags():
+            self._zero_carry = True             # ring full: what was pending is settled (synchronises) and remembered
+        slot = self._zero_next
+        self._zero_next = (slot + 1) % self._ZERO_FLAG_SLOTS
+        self._zero_flags[slot] = 0              # not pending: no copy into it is in flight
+        self._zero_pending.append(slot)
+        return slot
+
+    def _settle_zero_flags(self):
+        pending = getattr(self, "_zero_pending", None)
+        if not pending:
+            return False
+        self.sync()
+        hit = bool(self._zero_flags[pending].any())
+        pending.clear()
+        return hit
+
+    def any_deferred_zero(self):
+        """True if any dog_u8(report_zero="deferred") since the last call saw an input whose max() is 0.  Waits for the
+        stream (a no-op when the caller has just synchronised, e.g. by downloading scores)."""
+        hit = self._settle_zero_flags() or getattr(self, "_zero_carry", False)
+        self._zero_carry = False
+        return hit
 
     def nmi_scores(self, a, b, chunk=0):
         if a.dtype != np.uint8 or b.dtype != np.uint8 or a.size != b.size:

@@ -29,6 +29,10 @@ class _Level:
     features: Optional[Features] = None
 
 
+class _ZeroMaxImage(Exception):
+    """A dog() of the fast path met an input whose max() is 0: register() starts over in the careful mode."""
+
+
 class FeatureRegistrator:
     def __init__(self):
         self._ref_img = np.array([])
@@ -41,6 +45,7 @@ class FeatureRegistrator:
         self.verbose = True      # addition: the reference prints unconditionally
         self.compat_mov_getter = True   # the mov_img getter returns the REFERENCE image, as the reference's does; False: the moving image
         self._levels: List[_Level] = []   # reference side, coarsest first; kept for register(reuse_ref_img=True)
+        self._careful = False             # True: dog() synchronises for its max() == 0 report (see register())
 
     # -- inputs ---------------------------------------------------------------------------------------------
     @property
@@ -86,8 +91,36 @@ class FeatureRegistrator:
         check_img_is_provided(self._ref_img, "ref")
         check_img_is_provided(self._mov_img, "mov")
         check_img_dims_match(self._ref_img, self._mov_img)
+        # Fast path: dog() does not wait for the device to learn whether its input's max() is 0 (the reference's shortcut,
+        # :288-291); the flags are collected at the synchronisation points the rounds have anyway.  If one turns out set --
+        # an all-black level, a transform that moved everything out of view -- the call starts over in the careful mode,
+        # which asks after every dog() as the reference does.
+        if self._careful:
+            return self._register(reuse_ref_img)
+        import contextlib
+        import io
+        import sys
+        log = io.StringIO()     # the attempt's prints (this class's and the matchers') are shown once it stands
+        try:
+            with contextlib.redirect_stdout(log) if self.verbose else contextlib.nullcontext():
+                result = self._register(reuse_ref_img)
+            sys.stdout.write(log.getvalue())
+            return result
+        except _ZeroMaxImage:
+            self._levels = []
+            self._careful = True
+            try:
+                return self._register(False)
+            finally:
+                self._careful = False
+        except BaseException:
+            sys.stdout.write(log.getvalue())
+            raise
+
+    def _register(self, reuse_ref_img: bool) -> np.ndarray:
         if not (reuse_ref_img and self._levels):
             self.calc_ref_img_features()
+            self._check_deferred()
         moving = self._build_pyramid(self._mov_img)
         found: List[np.ndarray] = []            # one matrix per finished level, in full-resolution pixels
         for ref_level, (factor, mov_level) in zip(self._levels, moving):
@@ -174,6 +207,7 @@ class FeatureRegistrator:
                                                   self.tile_size, self.verbose)
             plausible = (affine_math.centre_stays_inside(estimate, mov_level.shape)
                          and affine_math.scales_plausible(estimate))
+            self._check_deferred()       # the gate has just synchronised: the flags of this round's dog() calls are in
             if any(improved) and plausible:
                 self._log("    Better alignment than before")
                 rounds.append(estimate)
@@ -194,7 +228,13 @@ class FeatureRegistrator:
         if not use_it:
             return img
         ctx = get_context()
+        if not self._careful and isinstance(img, DeviceArray):
+            return ctx.dog_u8(img, low_sigma, high_sigma, report_zero="deferred")
         out, src_max_is_zero = ctx.dog_u8(ctx.asdevice(img), low_sigma, high_sigma, report_zero=True)
         if src_max_is_zero:
             return img
         return out if isinstance(img, DeviceArray) else out.numpy()
+
+    def _check_deferred(self):
+        if not self._careful and get_context().any_deferred_zero():
+            raise _ZeroMaxImage()

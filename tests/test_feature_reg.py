@@ -447,6 +447,43 @@ def test_feature_registrator_helpers():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("zero", ["mov", "ref", "far"])
+def test_feature_registrator_zero_images_fall_back_to_the_careful_path(zero):
+    """register()'s fast path does not wait to learn whether a dog() input's max() is 0 (the reference's shortcut,
+    feature_registrator.py:288-291): the flags are read at the gate's synchronisation points and a set one restarts the call
+    in the careful mode.  An all-black moving image, an all-black reference, and a pair whose content the coarse estimate
+    throws out of view: the same matrix and the same log as the careful mode alone, printed once."""
+    import contextlib
+    import io
+    from microaligner_amd import FeatureRegistrator
+    H, W = 900, 1000
+    ref = synthetic.make_cells(H, W, seed=3)
+    mov = O.warp_affine(ref, np.array([[1.0, 0, 9.0], [0, 1.0, -6.0]]))
+    if zero == "mov":
+        mov = np.zeros_like(ref)
+    elif zero == "ref":
+        ref = np.zeros_like(ref)
+    else:
+        mov = np.zeros_like(ref)
+        mov[:40, :40] = ref[:40, :40]            # a corner of content: transforms may move it out of view
+
+    def run(careful):
+        f = FeatureRegistrator()
+        f.num_pyr_lvl, f.num_iterations, f.tile_size = 2, 2, 500
+        f._careful = careful
+        f.ref_img, f.mov_img = ref, mov
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            T = f.register()
+        assert f._careful == careful
+        return T, buf.getvalue()
+    fast, log_fast = run(False)
+    careful, log_careful = run(True)
+    assert np.array_equal(fast, careful) and log_fast == log_careful
+    assert log_fast.count("Pyramid factor") == 2
+
+
+@pytest.mark.gpu
 def test_affine_init_then_optical_flow_refine():
     """BASELINE cfg5 in miniature: feature-based affine initialisation, then the optical-flow refinement on the
     affinely aligned image (the reference pipeline's two stages, __main__.py:257-286 then :398-433)."""
