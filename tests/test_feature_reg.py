@@ -447,8 +447,9 @@ def test_feature_registrator_helpers():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
 @pytest.mark.parametrize("zero", ["mov", "ref", "far"])
-def test_feature_registrator_zero_images_fall_back_to_the_careful_path(zero):
+def test_feature_registrator_zero_images_fall_back_to_the_careful_path(zero, dtype):
     """register()'s fast path does not wait to learn whether a dog() input's max() is 0 (the reference's shortcut,
     feature_registrator.py:288-291): the flags are read at the gate's synchronisation points and a set one restarts the call
     in the careful mode.  An all-black moving image, an all-black reference, and a pair whose content the coarse estimate
@@ -457,7 +458,7 @@ def test_feature_registrator_zero_images_fall_back_to_the_careful_path(zero):
     import io
     from microaligner_amd import FeatureRegistrator
     H, W = 900, 1000
-    ref = synthetic.make_cells(H, W, seed=3)
+    ref = synthetic.make_cells(H, W, seed=3, dtype=dtype)
     mov = O.warp_affine(ref, np.array([[1.0, 0, 9.0], [0, 1.0, -6.0]]))
     if zero == "mov":
         mov = np.zeros_like(ref)
@@ -473,14 +474,19 @@ def test_feature_registrator_zero_images_fall_back_to_the_careful_path(zero):
         f._careful = careful
         f.ref_img, f.mov_img = ref, mov
         buf = io.StringIO()
-        with contextlib.redirect_stdout(buf):
-            T = f.register()
+        try:
+            with contextlib.redirect_stdout(buf):
+                T = f.register()
+        except ValueError as e:
+            # an all-zero image that is not uint8 comes out of dog() unchanged (:288-291) and FAST refuses it -- cv2.error in
+            # the reference, ValueError here -- in either mode
+            T = str(e)
         assert f._careful == careful
         return T, buf.getvalue()
     fast, log_fast = run(False)
     careful, log_careful = run(True)
-    assert np.array_equal(fast, careful) and log_fast == log_careful
-    assert log_fast.count("Pyramid factor") == 2
+    assert type(fast) is type(careful) and np.array_equal(fast, careful) and log_fast == log_careful
+    assert log_fast.count("Pyramid factor") <= 2
 
 
 @pytest.mark.gpu
