@@ -275,7 +275,16 @@ def estimate_affine_partial_2d(src_pts: np.ndarray, dst_pts: np.ndarray, confide
         a, b = (vx * ux + vy * uy) / den, (vy * ux - vx * uy) / den
         tx, ty = dx[i] - (a * sx[i] - b * sy[i]), dy[i] - (b * sx[i] + a * sy[i])
         ex, ey = a * sx - b * sy + tx - dx, b * sx + a * sy + ty - dy
-        mask = ex * ex + ey * ey < thr2
+        err = ex * ex + ey * ey
+        mask = err < thr2
+        if np.any(np.abs(err - thr2) < 1e-6):
+            # a point sits ON the threshold (keypoints are integer pixel positions: residuals of exactly 3 px happen): the
+            # closed form and the least-squares solve agree to ~1e-13 only, so the DEFINITION decides -- the same solve and
+            # the same expression as before round 5 (the inlier sets, hence every later step, stay bit-identical)
+            M = _fit_similarity(src[[i, j]], dst[[i, j]])
+            if M is None:
+                continue
+            mask = ((src @ M[:, :2].T + M[:, 2] - dst) ** 2).sum(1) < thr2
         count = int(np.count_nonzero(mask))
         if count > best_count:
             best_count, best_mask = count, mask

@@ -446,6 +446,67 @@ def test_feature_registrator_helpers():
         f.register()
 
 
+def _ransac_by_least_squares(src_pts, dst_pts, confidence=0.99, thr=3.0, max_iters=2000, seed=0):
+    """estimate_affine_partial_2d as it was stated before round 5: EVERY two-point sample fitted by the least-squares solve.
+    The product's loop fits the samples in closed form and lets this statement decide whenever a point sits on the threshold."""
+    src = np.asarray(src_pts, np.float64).reshape(-1, 2)
+    dst = np.asarray(dst_pts, np.float64).reshape(-1, 2)
+    n = len(src)
+    rng = np.random.default_rng(seed)
+    best_mask, best_count, iters, it = None, 0, max_iters, 0
+    while it < iters:
+        it += 1
+        i, j = rng.choice(n, 2, replace=False)
+        if np.allclose(src[i], src[j]):
+            continue
+        M = SP._fit_similarity(src[[i, j]], dst[[i, j]])
+        if M is None:
+            continue
+        mask = ((src @ M[:, :2].T + M[:, 2] - dst) ** 2).sum(1) < thr * thr
+        count = int(mask.sum())
+        if count > best_count:
+            best_count, best_mask = count, mask
+            w = count / n
+            denom = np.log(max(1.0 - w * w, 1e-12))
+            iters = min(max_iters, int(np.ceil(np.log(1.0 - confidence) / denom))) if denom < 0 else it
+    return best_mask
+
+
+def test_ransac_sampling_loop_equals_its_least_squares_statement_on_pixel_lattices():
+    """Keypoints are integer pixel positions, so residuals of EXACTLY the threshold (3 px) occur -- under a pure translation in
+    particular -- and a two-point model that differs in the last bit flips them.  The closed-form sample fits of round 5 must
+    select the very inlier sets the least-squares fits select (hence the same final matrix)."""
+    rng = np.random.default_rng(1)
+    for trial in range(120):
+        n = int(rng.integers(5, 2500))
+        th, sc = rng.uniform(-0.05, 0.05), rng.uniform(0.95, 1.05)
+        M = np.array([[sc * np.cos(th), -sc * np.sin(th), float(rng.integers(-30, 30))],
+                      [sc * np.sin(th), sc * np.cos(th), float(rng.integers(-30, 30))]])
+        if trial % 3 == 0:
+            M = np.array([[1, 0, float(rng.integers(-30, 30))], [0, 1, float(rng.integers(-30, 30))]], float)
+        src = rng.integers(0, 1500, (n, 2)).astype(np.float32)
+        dst = np.rint(src @ M[:, :2].T + M[:, 2] + rng.normal(0, 1.2, (n, 2))).astype(np.float32)
+        out = rng.random(n) < rng.uniform(0, 0.6)
+        dst[out] = rng.integers(0, 1500, (int(out.sum()), 2)).astype(np.float32)
+        est, mask = SP.estimate_affine_partial_2d(src, dst)
+        ref_mask = _ransac_by_least_squares(src, dst)
+        if est is None:
+            assert ref_mask is None or ref_mask.sum() < 2
+            continue
+        # the final matrix is the (iterated) least-squares fit on the selected inliers: equal selections, equal matrices
+        M2 = SP._fit_similarity(src.astype(np.float64)[ref_mask], dst.astype(np.float64)[ref_mask])
+        for _ in range(10):
+            m = ((src.astype(np.float64) @ M2[:, :2].T + M2[:, 2] - dst) ** 2).sum(1) < 9.0
+            if m.sum() < 2 or np.array_equal(m, ref_mask):
+                break
+            ref_mask = m
+            nxt = SP._fit_similarity(src.astype(np.float64)[m], dst.astype(np.float64)[m])
+            if nxt is None:
+                break
+            M2 = nxt
+        assert np.array_equal(mask, ref_mask) and np.array_equal(est, M2), trial
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
 @pytest.mark.parametrize("zero", ["mov", "ref", "far"])
