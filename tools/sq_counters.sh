@@ -56,7 +56,11 @@ for k in sorted(acc):
         print(f"   {c:34s} {d[c]:.5g}")
     g = lambda c: d.get(c, 0.0)
     if g("SQ_BUSY_CU_CYCLES"):
-        print(f"   -- VALU-active share of busy CU cycles     {g('SQ_ACTIVE_INST_VALU') * 4 / g('SQ_BUSY_CU_CYCLES'):.3f}   (ACTIVE_INST_* count quad-cycles)")
+        simd_cycles = 1024 * g("GRBM_GUI_ACTIVE") / 8      # 256 CUs x 4 SIMDs x the kernel's cycles (GRBM is summed over 8 XCDs)
+        if simd_cycles:
+            print(f"   -- VALU-busy: SIMD cycles executing a VALU instruction   {g('SQ_ACTIVE_INST_VALU') * 4 / simd_cycles:.3f}   (ACTIVE_INST_* count quad-cycles summed over waves)")
+            print(f"   -- wave slots occupied (of 16 per CU)       {g('SQ_WAVE_CYCLES') * 4 / (4096 * g('GRBM_GUI_ACTIVE') / 8):.3f}")
+            print(f"   -- clock                                    {g('GRBM_GUI_ACTIVE') / 8 / (ms * 1e6) if ms else 0:.3f} GHz (cycles of the GRBM pass / duration of pass 1)")
         print(f"   -- wave cycles waiting on an instruction    {g('SQ_WAIT_INST_ANY') / max(g('SQ_WAVE_CYCLES'), 1):.3f} of wave cycles; waiting on anything {g('SQ_WAIT_ANY') / max(g('SQ_WAVE_CYCLES'), 1):.3f}")
         print(f"   -- VMEM instructions in flight per wave     {g('SQ_INST_LEVEL_VMEM') / max(g('SQ_WAVE_CYCLES'), 1):.3f}")
         print(f"   -- LDS bank-conflict share of LDS cycles    {g('SQ_LDS_BANK_CONFLICT') / max(g('SQ_LDS_IDX_ACTIVE'), 1):.4f}")
