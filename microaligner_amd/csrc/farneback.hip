@@ -392,10 +392,12 @@ __global__ __launch_bounds__(64 * NW, BV_WAVES) void fb_blur_v_stream(FbGeom g, 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Ph = g.t.Ph, Pw = g.t.Pw;
     const int nbx = (Pw + 63) / 64;
-    const int nslots = (int)(((nplanes + 7) / 8) * 8);
-    const int item = d_xcd_work_item(blockIdx.x, nbx * nslots);
+    // plain dispatch order (round 5): the strips of this form share no halo, so nothing is gained by keeping neighbours on one
+    // XCD, and the V rows they write leave faster through eight L2s than through one (24.0 -> 23.7 ms per step; the expansion
+    // kernel shows the same preference, profiles/r05_notes.md).  The tiled form above keeps the XCD-aware list for its halos.
+    const int item = blockIdx.x;
     const int bx = item % nbx;
-    const int bz = d_xcd_unit(item / nbx, nplanes);
+    const int bz = item / nbx;
     if (bz >= nplanes) return;
     const int wl = bz / 5, ch = bz - wl * 5;
     const float* src = plane_ptr(ws, g, wl, PL_M + ch);
@@ -912,8 +914,8 @@ int run_batch(ma_ctx* ctx, const T* prev, const T* next, FbGeom g, int nwin, con
                 // the streaming form needs whole tap groups (m % (R/2) == 0: the reference's window of 99) and its ring in LDS
                 const size_t lds_vs = (size_t)(BVS_NW * BV_R + 2 * m + 4 + 3 * (BV_R / 2) + 1) * 64 * sizeof(float);
                 if (m % (BV_R / 2) == 0 && lds_vs <= LDS_MAX) {
-                    const long long items = (long long)((Pw + 63) / 64) * ma_xcd_slots(nwin * 5);
-                    hipLaunchKernelGGL((fb_blur_v_stream<BV_R, BVS_NW, FUSED>), dim3(ma_xcd_grid(items)), dim3(64 * BVS_NW),
+                    const long long items = (long long)((Pw + 63) / 64) * nwin * 5;
+                    hipLaunchKernelGGL((fb_blur_v_stream<BV_R, BVS_NW, FUSED>), dim3((unsigned)items), dim3(64 * BVS_NW),
                                        lds_vs, ctx->stream, g, m, taps, ws, nwin * 5, reach);
                 } else {
                     const long long items = (long long)((Pw + 63) / 64) * ((Ph + BV_NW * BV_R - 1) / (BV_NW * BV_R)) * ma_xcd_slots(nwin * 5);
