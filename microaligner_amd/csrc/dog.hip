@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void scale_to_u8(const T* __restrict__ src, si
             const T* s = src + 4 * i;
             x0 = (float)s[0]; x1 = (float)s[1]; x2 = (float)s[2]; x3 = (float)s[3];
         }
-        reinterpret_cast<unsigned*>(dst)[i] = cvt(x0) | (cvt(x1) << 8) | (cvt(x2) << 16) | (cvt(x3) << 24);
+        __builtin_nontemporal_store(cvt(x0) | (cvt(x1) << 8) | (cvt(x2) << 16) | (cvt(x3) << 24), &reinterpret_cast<unsigned*>(dst)[i]);
     }
     for (size_t i = n4 * 4 + tid; i < n; i += stride) dst[i] = (uint8_t)cvt((float)src[i]);
 }

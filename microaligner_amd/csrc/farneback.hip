@@ -180,7 +180,10 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
     const int rtxh = d_reflect101(x0 - 2 + hc4, Pw);
     const int tcxh = d_clamp(d_clamp(x0 - 1 + hc2, 0, Pw - 1) - (x0 - 2), 1, RW - 2);
 
-    // stores go through one buffer resource spanning the window's planes (plane offsets in SGPRs)
+    // stores go through one buffer resource spanning the window's planes (plane offsets in SGPRs), NON-TEMPORAL (round 5): the
+    // kernel is bound by its 60 B/px of writes, nothing reads them before 8 GB of other planes have gone by, and with the
+    // `nt` policy the 15 write streams of a block no longer fight for L2 lines: 6.68 -> 5.76 ms per step (5.7 TB/s)
+    constexpr int ST_NT = 2;
     const int plane4 = (int)(g.plane * sizeof(float));
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(plane_ptr(ws, g, wl, 0), 0, PL_COUNT * plane4, 0x00020000);
     // block whose 20 x 68 raw tile needs neither reflection nor zero padding
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
 #pragma unroll
                 for (int k = 0; k < 5; k++)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(R[k]), wrsrc, pix4,
-                                                          ((img == 0 ? PL_R0 : PL_R1) + k) * plane4, 0);
+                                                          ((img == 0 ? PL_R0 : PL_R1) + k) * plane4, ST_NT);
             }
             if (img == 0) {
 #pragma unroll
@@ -293,7 +296,7 @@ __global__ __launch_bounds__(K1_THREADS, 4) void fb_polyexp_m0(const T* __restri
                 update_matrices_px(r0v[rr], R[0], R[1], R[2], R[3], R[4], inside, 0.f, 0.f, x, y, Pw, Ph, Mv);
 #pragma unroll
                 for (int k = 0; k < 5; k++)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Mv[k]), wrsrc, pix4, (PL_M + k) * plane4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Mv[k]), wrsrc, pix4, (PL_M + k) * plane4, ST_NT);
             }
         }
         __syncthreads();

@@ -185,8 +185,11 @@ __global__ __launch_bounds__(256) void pyr_up_flow_kernel(const float2* __restri
         bot.w = ((od[r + 1].y + od[r + 2].y) * 4) * (1.f / 64);
         float2* d0 = dst + (size_t)(2 * (y0 + r)) * dw + X;
         if ((dw & 1) == 0) {
-            *reinterpret_cast<float4*>(d0) = top;
-            *reinterpret_cast<float4*>(d0 + dw) = bot;
+            // non-temporal: the upsampled flow (2.1 GB at full resolution) is read again only after other kernels have run
+            // (0.91 -> 0.76 ms per step, profiles/r05_notes.md)
+            typedef float nt_f4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store((nt_f4){top.x, top.y, top.z, top.w}, reinterpret_cast<nt_f4*>(d0));
+            __builtin_nontemporal_store((nt_f4){bot.x, bot.y, bot.z, bot.w}, reinterpret_cast<nt_f4*>(d0 + dw));
         } else {
             d0[0] = make_float2(top.x, top.y); d0[1] = make_float2(top.z, top.w);
             d0[dw] = make_float2(bot.x, bot.y); d0[dw + 1] = make_float2(bot.z, bot.w);
