@@ -86,7 +86,7 @@ def find_features(img: np.ndarray, nfeatures_limit: int = 5000) -> Features:
     return features
 
 
-def match_features(img1_features: Features, img2_features: Features, verbose: bool = True, knn=None) -> np.ndarray:
+def match_features(img1_features: Features, img2_features: Features, verbose: bool = True, knn=None, log=print) -> np.ndarray:
     """feature_detection.py:123-158: 2-NN of every descriptor of image 2 among those of image 1, ratio test, then
     the similarity transform that maps image-2 points onto image-1 points.  Identity when there is too little to
     go on; None (as cv2 does) when the fit itself fails is mapped to identity as well.
@@ -106,7 +106,7 @@ def match_features(img1_features: Features, img2_features: Features, verbose: bo
     idx, dist = search(des2, des1)
     good = np.nonzero(dist[:, 0] < RATIO * dist[:, 1])[0]
     if verbose:
-        print("    Good matches", len(good), "/", len(des2))
+        log("    Good matches", len(good), "/", len(des2))   # log: where the line goes (print, or a registrator's buffer)
     if len(good) < 3:
         return identity
     src_pts = pts1[idx[good, 0]].astype(np.float32)

@@ -46,6 +46,7 @@ class FeatureRegistrator:
         self.compat_mov_getter = True   # the mov_img getter returns the REFERENCE image, as the reference's does; False: the moving image
         self._levels: List[_Level] = []   # reference side, coarsest first; kept for register(reuse_ref_img=True)
         self._careful = False             # True: dog() synchronises for its max() == 0 report (see register())
+        self._log_buf = None              # list of held-back log lines during the fast attempt of register()
 
     # -- inputs ---------------------------------------------------------------------------------------------
     @property
@@ -69,8 +70,13 @@ class FeatureRegistrator:
         self._mov_img = img
 
     def _log(self, *args):
+        # in the fast attempt of register() the lines are kept back until the attempt stands (per object: no process-wide
+        # redirection of stdout, which threads registering side by side would trip over)
         if self.verbose:
-            print(*args)
+            if self._log_buf is not None:
+                self._log_buf.append(" ".join(str(a) for a in args))
+            else:
+                print(*args)
 
     @property
     def level_factors(self) -> List[int]:
@@ -97,25 +103,22 @@ class FeatureRegistrator:
         # which asks after every dog() as the reference does.
         if self._careful:
             return self._register(reuse_ref_img)
-        import contextlib
-        import io
-        import sys
-        log = io.StringIO()     # the attempt's prints (this class's and the matchers') are shown once it stands
+        self._log_buf = []      # the attempt's lines (this class's and the matchers') are shown once it stands
         try:
-            with contextlib.redirect_stdout(log) if self.verbose else contextlib.nullcontext():
-                result = self._register(reuse_ref_img)
-            sys.stdout.write(log.getvalue())
-            return result
+            result = self._register(reuse_ref_img)
         except _ZeroMaxImage:
+            self._log_buf = None
             self._levels = []
             self._careful = True
             try:
                 return self._register(False)
             finally:
                 self._careful = False
-        except BaseException:
-            sys.stdout.write(log.getvalue())
-            raise
+        finally:
+            held, self._log_buf = self._log_buf, None
+            for line in held or ():
+                print(line)
+        return result
 
     def _register(self, reuse_ref_img: bool) -> np.ndarray:
         if not (reuse_ref_img and self._levels):
@@ -200,11 +203,11 @@ class FeatureRegistrator:
         for it in range(self.num_iterations):
             self._log("    Iteration", it + 1, "/", self.num_iterations)
             # the exact 2-NN search over up to 45 000 x 45 000 descriptors runs on the device (ma_knn2_l2)
-            estimate = register_img_pair(ref_level.features, self._features_of(current), self.verbose, knn=ctx.knn2)
+            estimate = register_img_pair(ref_level.features, self._features_of(current), self.verbose, knn=ctx.knn2, log=self._log)
             is_identity = bool(np.array_equal(estimate, affine_math.IDENTITY))
             candidate = current if is_identity else self.transform_img(current, estimate)
             improved = check_if_higher_similarity(ref_gate, self.dog(candidate, True), self.dog(current, True),
-                                                  self.tile_size, self.verbose)
+                                                  self.tile_size, self.verbose, log=self._log)
             plausible = (affine_math.centre_stays_inside(estimate, mov_level.shape)
                          and affine_math.scales_plausible(estimate))
             self._check_deferred()       # the gate has just synchronised: the flags of this round's dog() calls are in

@@ -93,8 +93,8 @@ def mutual_information_test(ref_arr, test_arr, init_arr, tile_size: int) -> Tupl
     return after_mi_score, before_mi_score
 
 
-def check_if_higher_similarity(ref_arr, test_arr, init_arr, tile_size: int, verbose: bool = True) -> List[bool]:
+def check_if_higher_similarity(ref_arr, test_arr, init_arr, tile_size: int, verbose: bool = True, log=print) -> List[bool]:
     after, before = mutual_information_test(ref_arr, test_arr, init_arr, tile_size)
     if verbose:
-        print("    MI score after:", after, "| MI score before:", before)
+        log("    MI score after:", after, "| MI score before:", before)
     return [after > before]
