@@ -141,7 +141,9 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: b
             os.unlink(path)
     if page_locked == "all" or (page_locked and (ws == 1 or arr.ndim < 2)):
         _page_lock(arr, [arr])
-    elif page_locked:
+    elif page_locked and arr.shape[0] and arr[0].nbytes >= (1 << 20):
+        # (rows of less than 1 MiB are not units of work: thousands of small registrations would cost more than they save --
+        # such an array is page-locked as a whole on request, page_locked="all")
         _page_lock(arr, [arr[i] for i in range(rank, arr.shape[0], ws)])
     return arr
 
