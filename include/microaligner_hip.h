@@ -155,6 +155,11 @@ int ma_host_free(void* hptr);
  * must stay mapped until ma_host_unregister; each process registers its own mapping of shared memory. */
 int ma_host_register(void* hptr, size_t bytes);
 int ma_host_unregister(void* hptr);
+/* How a transfer of [hptr, hptr + bytes) will be carried out: *direct = 1 when the WHOLE range is page-locked (inside one
+ * ma_host_register registration, or inside one allocation the HIP runtime reports as host memory) and goes by DMA as it
+ * is; 0 when any part of it is pageable or of unknown extent -- e.g. a copy that starts inside a registered row of a shared
+ * array and runs past its end -- and the transfer is staged through the ctx's page-locked ring. */
+int ma_host_transfer_is_direct(const void* hptr, size_t bytes, int* direct);
 int ma_memset(ma_ctx* ctx, void* dst, int value, size_t bytes);
 
 /* ---- timing (HIP events on the ctx stream) ------------------------------ */
@@ -384,6 +389,22 @@ enum ma_knn_mode { MA_KNN_AUTO = 0, MA_KNN_EXACT = 1, MA_KNN_FILTERED = 2 };
 int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const float* train, int nt, int dim, int* idx_out,
                   float* dist_out, int mode, int* uncertified_host);
 
+/* Matching step after the 2-NN search (feature_detection.py:142-158): Lowe's ratio test sqrt(d0) < ratio * sqrt(d1) over the
+ * (squared) distances ma_knn2_l2 left on the device, then the counterpart of cv.estimateAffinePartial2D(query points -> train
+ * points, RANSAC, confidence) -- bit for bit microaligner_amd/feature_reg/sparse_cpu.py:estimate_affine_partial_2d, whose
+ * random sequence numpy's Generator(PCG64(seed)) defines: rng_state = {state hi, state lo, inc hi, inc lo} of
+ * numpy.random.PCG64(seed).state.  idx / dist_sq: (nq, 2) device arrays; query_pts / train_pts: (n, 2) float64 (x, y) device
+ * arrays.  Results on the host: the 2 x 3 matrix (row major), the number of good matches and
+ * status 0 = matrix valid, 1 = fewer than 3 good matches (the reference returns the identity), 2 = no model (cv2 returns
+ * None), 3 = coordinates not integer-valued or too large for exact sums: not computed, use the host statement. */
+int ma_match_similarity(ma_ctx* ctx, const int* idx, const float* dist_sq, int nq, const double* query_pts,
+                        const double* train_pts, int nt, float ratio, double confidence, double reproj_threshold,
+                        int max_iters, const unsigned long long rng_state[4], double* m2x3_host, int* n_good_host,
+                        int* status_host);
+/* Host-only pieces of the above, exported for the CPU tests: `count` draws of Generator.choice(n, 2, replace=False) from the
+ * given PCG64 state (pairs_out: count x 2), and the adaptive iteration count of the RANSAC loop. */
+int ma_host_pcg64_choice2(const unsigned long long state[4], int n, int count, int* pairs_out);
+int ma_host_ransac_iterations(int count, int n, double confidence, int max_iters, int it, int* iters);
 /* ---- dense halves of the feature stage (FeatureRegistrator), batched over nt square tiles of side P ----
  * ma_fast_nms: FAST-9/16 corner score of the tile interiors (tile[margin:-margin, margin:-margin], as
  * feature_detection.py:105 cuts them) kept only at strict 3x3 local maxima -- the pixels

@@ -44,6 +44,7 @@ SIGNATURES = {
     "ma_host_free": (_i, [_vp]),
     "ma_host_register": (_i, [_vp, _sz]),
     "ma_host_unregister": (_i, [_vp]),
+    "ma_host_transfer_is_direct": (_i, [_vp, _sz, C.POINTER(C.c_int)]),
     "ma_memset": (_i, [_vp, _vp, _i, _sz]),
     "ma_event_create": (_i, [_vp, C.POINTER(_vp)]),
     "ma_event_destroy": (_i, [_vp, _vp]),
@@ -76,6 +77,10 @@ SIGNATURES = {
     "ma_warp_affine_cv": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(_d), _i, _i, _vp]),
     "ma_knn2_l2": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "ma_knn2_l2_ex": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "ma_match_similarity": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _d, _d, _i, C.POINTER(C.c_ulonglong), C.POINTER(_d),
+                                 C.POINTER(_i), C.POINTER(_i)]),
+    "ma_host_pcg64_choice2": (_i, [C.POINTER(C.c_ulonglong), _i, _i, C.POINTER(_i)]),
+    "ma_host_ransac_iterations": (_i, [_i, _i, _d, _i, _i, C.POINTER(_i)]),
     "ma_fast_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ma_daisy_describe": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.POINTER(_d)), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d),
                                _vp, _vp, _i, _vp]),

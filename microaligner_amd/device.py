@@ -769,12 +769,14 @@ class Context:
         self._run(self.lib.ma_warp_affine_cv, img.ptr, _dt(img.dtype), h, w, mm, dh, dw, out.ptr)
         return out
 
-    def knn2(self, query, train, mode="auto", stats=None):
+    def knn2(self, query, train, mode="auto", stats=None, on_device=False):
         """Exact 2-NN (L2) of every row of `query` among the rows of `train`: (idx (n, 2) int64, dist (n, 2) float32)
         on the host, like feature_reg.sparse_cpu.knn2.  Either side may be a host array or a DeviceArray (descriptors
         that ma_daisy_describe left on the device are searched where they are).
         mode: "auto" | "exact" | "filtered" (ma_knn2_l2_ex: matrix-core shortlist + exact re-evaluation + certificate;
-        the same result bit for bit); stats: a dict that receives {"uncertified": queries served by the exact fallback}."""
+        the same result bit for bit); stats: a dict that receives {"uncertified": queries served by the exact fallback}.
+        on_device: leave the results where they are -- (idx (n, 2) int32 bits, SQUARED dist (n, 2) float32) device buffers, what
+        match_similarity takes."""
         modes = {"auto": L.MA_KNN_AUTO, "exact": L.MA_KNN_EXACT, "filtered": L.MA_KNN_FILTERED}
         if mode not in modes:
             raise ValueError(f"unknown search mode {mode!r}: auto, exact or filtered")
@@ -799,9 +801,34 @@ class Context:
                   C.byref(unc) if stats is not None else None)
         if stats is not None:
             stats["uncertified"] = unc.value
+        if on_device:
+            return idx, dist
         out_i = np.empty((nq, 2), np.int32)
         L.check(self.lib.ma_memcpy_d2h(self.handle, out_i.ctypes.data, idx.ptr, out_i.nbytes))
         return out_i.astype(np.int64), np.sqrt(dist.numpy())   # the kernel returns squared distances
+
+    _PCG64_STATES = {}
+
+    def match_similarity(self, idx, dist_sq, query_pts, train_pts, ratio=0.5, confidence=0.99, reproj_threshold=3.0,
+                         max_iters=2000, seed=0):
+        """Ratio test + RANSAC similarity fit on the device (ma_match_similarity) over what knn2(on_device=True) left there:
+        bit for bit feature_reg.sparse_cpu.estimate_affine_partial_2d(query points of the good matches, their train points).
+        query_pts / train_pts: (n, 2) float64 device buffers (x, y).  Returns (matrix (2, 3) float64 or None, n_good, status);
+        status as in include/microaligner_hip.h: 0 ok, 1 fewer than 3 good matches, 2 no model, 3 not computed (use the host)."""
+        st = self._PCG64_STATES.get(seed)
+        if st is None:     # numpy's seeding (SeedSequence -> PCG64) stays numpy's: only the stream is restated in C
+            raw = np.random.PCG64(seed).state["state"]
+            m64 = (1 << 64) - 1
+            st = self._PCG64_STATES[seed] = (C.c_ulonglong * 4)(raw["state"] >> 64, raw["state"] & m64, raw["inc"] >> 64,
+                                                                raw["inc"] & m64)
+        nq = int(idx.nbytes // 8)             # (nq, 2) int32, typed (knn2) or raw (tests)
+        mat = (C.c_double * 6)()
+        n_good, status = C.c_int(0), C.c_int(0)
+        self._run(self.lib.ma_match_similarity, idx.ptr, dist_sq.ptr, nq, query_pts.ptr, train_pts.ptr,
+                  int(train_pts.nbytes // 16), float(ratio), float(confidence), float(reproj_threshold), int(max_iters), st, mat,
+                  C.byref(n_good), C.byref(status))
+        m = np.array(mat, np.float64).reshape(2, 3) if status.value == 0 else None
+        return m, n_good.value, status.value
 
     def cut_tiles(self, img, tile, overlap, first_tile, n_tiles):
         """The zero-padded feature windows first_tile .. first_tile + n_tiles of a uint8 device image: (n, P, P)."""

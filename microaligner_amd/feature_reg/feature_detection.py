@@ -63,6 +63,12 @@ class Features:
     def is_valid(self) -> bool:
         return self.pts is not None and self._descriptors is not None
 
+    def device_pts(self, ctx):
+        """The keypoint positions as an (n, 2) float64 device buffer (uploaded once per Features object)."""
+        if getattr(self, "_pts_dev", None) is None:
+            self._pts_dev = ctx._upload_raw(np.ascontiguousarray(self.pts, np.float64))
+        return self._pts_dev
+
 
 def view_tile_without_overlap(img, overlap):
     return img[overlap:-overlap, overlap:-overlap]
@@ -86,15 +92,29 @@ def find_features(img: np.ndarray, nfeatures_limit: int = 5000) -> Features:
     return features
 
 
-def match_features(img1_features: Features, img2_features: Features, verbose: bool = True, knn=None, log=print) -> np.ndarray:
+def match_features(img1_features: Features, img2_features: Features, verbose: bool = True, knn=None, log=print, ctx=None) -> np.ndarray:
     """feature_detection.py:123-158: 2-NN of every descriptor of image 2 among those of image 1, ratio test, then
     the similarity transform that maps image-2 points onto image-1 points.  Identity when there is too little to
     go on; None (as cv2 does) when the fit itself fails is mapped to identity as well.
-    knn: the 2-NN search, (query, train) -> (idx, dist); FeatureRegistrator passes the device search
-    (Context.knn2 -> ma_knn2_l2), the default is the host one (sparse_cpu.knn2)."""
+    knn: the 2-NN search, (query, train) -> (idx, dist); the default is the host one (sparse_cpu.knn2).
+    ctx: a device context -- the whole step runs there (Context.knn2 -> ma_knn2_l2 leaves its pairs on the device,
+    Context.match_similarity -> ma_match_similarity does the ratio test and the RANSAC fit on them, bit for bit the host
+    statement below); only the matrix and the number of good matches come back."""
     identity = np.eye(2, 3)
     if not img1_features.is_valid() or not img2_features.is_valid():
         return identity
+    if ctx is not None:
+        des1, des2 = img1_features.descriptors_for_search, img2_features.descriptors_for_search
+        if len(des1) < 2:
+            return identity
+        idx_d, dist_d = ctx.knn2(des2, des1, on_device=True)
+        mat, n_good, status = ctx.match_similarity(idx_d, dist_d, img2_features.device_pts(ctx), img1_features.device_pts(ctx),
+                                                   ratio=RATIO, confidence=0.99)
+        if status != 3:
+            if verbose:
+                log("    Good matches", n_good, "/", len(des2))
+            return identity if mat is None else mat
+        knn = ctx.knn2            # coordinates the device path does not take (not integer-valued): the host statement decides
     search = knn or knn2
     pts1, pts2 = img1_features.pts, img2_features.pts
     if knn is not None:     # the device search takes the descriptors where they are

@@ -202,8 +202,9 @@ class FeatureRegistrator:
         current = mov_level
         for it in range(self.num_iterations):
             self._log("    Iteration", it + 1, "/", self.num_iterations)
-            # the exact 2-NN search over up to 45 000 x 45 000 descriptors runs on the device (ma_knn2_l2)
-            estimate = register_img_pair(ref_level.features, self._features_of(current), self.verbose, knn=ctx.knn2, log=self._log)
+            # the exact 2-NN search over up to 45 000 x 45 000 descriptors, the ratio test and the RANSAC fit run on the device
+            # (ma_knn2_l2, ma_match_similarity): the matrix and the match count come back
+            estimate = register_img_pair(ref_level.features, self._features_of(current), self.verbose, log=self._log, ctx=ctx)
             is_identity = bool(np.array_equal(estimate, affine_math.IDENTITY))
             candidate = current if is_identity else self.transform_img(current, estimate)
             improved = check_if_higher_similarity(ref_gate, self.dog(candidate, True), self.dog(current, True),

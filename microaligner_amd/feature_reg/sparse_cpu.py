@@ -234,23 +234,70 @@ def _knn2_blocks(q, t, tn, idx, dist, block):
 
 
 def _fit_similarity(src: np.ndarray, dst: np.ndarray) -> Optional[np.ndarray]:
-    """Least-squares 4-DOF transform dst ~ [[a, -b, tx], [b, a, ty]] @ (src, 1)."""
+    """Least-squares 4-DOF transform dst ~ [[a, -b, tx], [b, a, ty]] @ (src, 1), in closed form.
+
+    The normal equations of  sum |a x - b y + tx - u|^2 + |b x + a y + ty - v|^2  about an integer-valued centre
+    (cx, cy, cu, cv) = floor(mean):  a = (n Sxu - (Sx Su + Sy Sv)) / D,  b = (n Sxv - (Sx Sv - Sy Su)) / D,
+    D = n Sxx - (Sx^2 + Sy^2)  with the centred sums  Sx = sum x', Sxx = sum (x'^2 + y'^2), Sxu = sum (x' u' + y' v'),
+    Sxv = sum (x' v' - y' u').  Keypoints are integer pixel positions: every term and every partial sum is an integer below
+    2^53, i.e. EXACT in float64 in any summation order -- which is what lets the device (csrc/ransac.hip, a parallel
+    reduction) and this file (numpy's pairwise sums) produce the same bits.  The few operations after the sums are written
+    out one by one in the order the kernel uses.  None when the source points coincide (rank < 4)."""
     n = len(src)
-    A = np.zeros((2 * n, 4))
-    A[0::2, 0], A[0::2, 1], A[0::2, 2] = src[:, 0], -src[:, 1], 1.0
-    A[1::2, 0], A[1::2, 1], A[1::2, 3] = src[:, 1], src[:, 0], 1.0
-    sol, _, rank, _ = np.linalg.lstsq(A, dst.reshape(-1), rcond=None)
-    if rank < 4:
+    if n < 2:
         return None
-    a, b, tx, ty = sol
+    x, y, u, v = src[:, 0], src[:, 1], dst[:, 0], dst[:, 1]
+    fn = float(n)
+    cx, cy = float(np.floor(x.sum() / fn)), float(np.floor(y.sum() / fn))
+    cu, cv = float(np.floor(u.sum() / fn)), float(np.floor(v.sum() / fn))
+    x, y, u, v = x - cx, y - cy, u - cu, v - cv
+    Sx, Sy, Su, Sv = float(x.sum()), float(y.sum()), float(u.sum()), float(v.sum())
+    Sxx = float((x * x + y * y).sum())
+    Sxu = float((x * u + y * v).sum())
+    Sxv = float((x * v - y * u).sum())
+    D = fn * Sxx - (Sx * Sx + Sy * Sy)
+    if not D > 0.0:
+        return None
+    a = (fn * Sxu - (Sx * Su + Sy * Sv)) / D
+    b = (fn * Sxv - (Sx * Sv - Sy * Su)) / D
+    tx = (Su - (a * Sx - b * Sy)) / fn          # translation between the centred frames ...
+    ty = (Sv - (b * Sx + a * Sy)) / fn
+    tx = (tx + cu) - (a * cx - b * cy)          # ... and between the original ones
+    ty = (ty + cv) - (b * cx + a * cy)
     return np.array([[a, -b, tx], [b, a, ty]], np.float64)
+
+
+def _similarity_inliers(M, sx, sy, dx, dy, thr2):
+    """Points whose squared residual under M is below thr2; the expression the RANSAC loop, the refinement and the device
+    kernel share: ex = ((a x - b y) + tx) - u, ey = ((b x + a y) + ty) - v, err = ex ex + ey ey, products and sums rounded
+    one by one (no fused multiply-add, no BLAS)."""
+    a, b, tx, ty = float(M[0, 0]), float(M[1, 0]), float(M[0, 2]), float(M[1, 2])
+    ex, ey = a * sx - b * sy + tx - dx, b * sx + a * sy + ty - dy
+    return ex * ex + ey * ey < thr2
+
+
+def ransac_iterations(count: int, n: int, confidence: float, max_iters: int, it: int) -> int:
+    """Iterations RANSAC still needs once a model with `count` inliers of `n` points has been seen (two-point samples):
+    ceil(log(1 - confidence) / log(1 - w^2)), w = count / n, at most max_iters; `it` (stop now) when every point is an
+    inlier.  math.log, i.e. the C library's: the host half of the device path (csrc/ransac.hip) calls the same function."""
+    import math
+    w = count / n
+    denom = math.log(max(1.0 - w * w, 1e-12))
+    return min(max_iters, int(math.ceil(math.log(1.0 - confidence) / denom))) if denom < 0 else it
 
 
 def estimate_affine_partial_2d(src_pts: np.ndarray, dst_pts: np.ndarray, confidence: float = 0.99,
                                reproj_threshold: float = 3.0, max_iters: int = 2000, seed: int = 0):
     """Counterpart of cv.estimateAffinePartial2D(src, dst, method=RANSAC, confidence=0.99): similarity transform
     (rotation, uniform scale, translation) mapping src to dst, robust to outliers.  Returns (2x3 matrix or None,
-    inlier mask)."""
+    inlier mask).
+
+    This function is the DEFINITION the device path (Context.match_similarity -> ma_match_similarity, csrc/ransac.hip)
+    reproduces bit for bit: samples are numpy's Generator(PCG64(seed)).choice(n, 2, replace=False) in sequence; a sample's
+    model is the similarity through its two point pairs in closed form; inliers by _similarity_inliers; the iteration count
+    adapts by ransac_iterations; the best sample's inliers are refitted by _fit_similarity and re-selected until the set
+    is stable (at most 10 times).  OpenCV's own estimator has the same structure (two-point closed-form kernel, adaptive
+    iteration count, refinement on the inliers) with its own random sequence and a Levenberg-Marquardt refinement."""
     src = np.asarray(src_pts, np.float64).reshape(-1, 2)
     dst = np.asarray(dst_pts, np.float64).reshape(-1, 2)
     n = len(src)
@@ -266,8 +313,7 @@ def estimate_affine_partial_2d(src_pts: np.ndarray, dst_pts: np.ndarray, confide
         # np.allclose(src[i], src[j]) spelled out (its call overhead was a third of a RANSAC round)
         if (abs(sx[i] - sx[j]) <= 1e-8 + 1e-5 * abs(sx[j])) and (abs(sy[i] - sy[j]) <= 1e-8 + 1e-5 * abs(sy[j])):
             continue
-        # the similarity through two point pairs in closed form: z = (q1 - q0) / (p1 - p0) as complex numbers, t = q0 - z p0
-        # (the least-squares solve of the same 4 x 4 system took 0.14 ms per sample in numpy)
+        # the similarity through two point pairs: z = (q1 - q0) / (p1 - p0) as complex numbers, t = q0 - z p0
         ux, uy, vx, vy = sx[j] - sx[i], sy[j] - sy[i], dx[j] - dx[i], dy[j] - dy[i]
         den = ux * ux + uy * uy
         if den == 0.0:
@@ -275,31 +321,19 @@ def estimate_affine_partial_2d(src_pts: np.ndarray, dst_pts: np.ndarray, confide
         a, b = (vx * ux + vy * uy) / den, (vy * ux - vx * uy) / den
         tx, ty = dx[i] - (a * sx[i] - b * sy[i]), dy[i] - (b * sx[i] + a * sy[i])
         ex, ey = a * sx - b * sy + tx - dx, b * sx + a * sy + ty - dy
-        err = ex * ex + ey * ey
-        mask = err < thr2
-        if np.any(np.abs(err - thr2) < 1e-6):
-            # a point sits ON the threshold (keypoints are integer pixel positions: residuals of exactly 3 px happen): the
-            # closed form and the least-squares solve agree to ~1e-13 only, so the DEFINITION decides -- the same solve and
-            # the same expression as before round 5 (the inlier sets, hence every later step, stay bit-identical)
-            M = _fit_similarity(src[[i, j]], dst[[i, j]])
-            if M is None:
-                continue
-            mask = ((src @ M[:, :2].T + M[:, 2] - dst) ** 2).sum(1) < thr2
+        mask = ex * ex + ey * ey < thr2
         count = int(np.count_nonzero(mask))
         if count > best_count:
             best_count, best_mask = count, mask
-            w = count / n
-            denom = np.log(max(1.0 - w * w, 1e-12))
-            iters = min(max_iters, int(np.ceil(np.log(1.0 - confidence) / denom))) if denom < 0 else it
+            iters = ransac_iterations(count, n, confidence, max_iters, it)
     if best_mask is None or best_count < 2:
         return None, np.zeros(n, bool)
     M = _fit_similarity(src[best_mask], dst[best_mask])
     if M is None:
         return None, best_mask
     for _ in range(10):     # re-select the inliers of the refined model (OpenCV refines on the inlier set)
-        err = ((src @ M[:, :2].T + M[:, 2] - dst) ** 2).sum(1)
-        mask = err < thr2
-        if mask.sum() < 2 or np.array_equal(mask, best_mask):
+        mask = _similarity_inliers(M, sx, sy, dx, dy, thr2)
+        if np.count_nonzero(mask) < 2 or np.array_equal(mask, best_mask):
             break
         best_mask = mask
         M2 = _fit_similarity(src[mask], dst[mask])

@@ -53,5 +53,6 @@ def find_features(img: np.ndarray, tile_size: int, ctx=None) -> Features:
     return combine_features(per_tile, info["ntiles"]["x"], info["ntiles"]["y"], tile_w, tile_h)
 
 
-def register_img_pair(ref_combined_features: Features, mov_combined_features: Features, verbose: bool = True, knn=None, log=print):
-    return match_features(ref_combined_features, mov_combined_features, verbose, knn, log)
+def register_img_pair(ref_combined_features: Features, mov_combined_features: Features, verbose: bool = True, knn=None, log=print,
+                      ctx=None):
+    return match_features(ref_combined_features, mov_combined_features, verbose, knn, log, ctx)

@@ -446,65 +446,126 @@ def test_feature_registrator_helpers():
         f.register()
 
 
-def _ransac_by_least_squares(src_pts, dst_pts, confidence=0.99, thr=3.0, max_iters=2000, seed=0):
-    """estimate_affine_partial_2d as it was stated before round 5: EVERY two-point sample fitted by the least-squares solve.
-    The product's loop fits the samples in closed form and lets this statement decide whenever a point sits on the threshold."""
-    src = np.asarray(src_pts, np.float64).reshape(-1, 2)
-    dst = np.asarray(dst_pts, np.float64).reshape(-1, 2)
-    n = len(src)
-    rng = np.random.default_rng(seed)
-    best_mask, best_count, iters, it = None, 0, max_iters, 0
-    while it < iters:
-        it += 1
-        i, j = rng.choice(n, 2, replace=False)
-        if np.allclose(src[i], src[j]):
-            continue
-        M = SP._fit_similarity(src[[i, j]], dst[[i, j]])
-        if M is None:
-            continue
-        mask = ((src @ M[:, :2].T + M[:, 2] - dst) ** 2).sum(1) < thr * thr
-        count = int(mask.sum())
-        if count > best_count:
-            best_count, best_mask = count, mask
-            w = count / n
-            denom = np.log(max(1.0 - w * w, 1e-12))
-            iters = min(max_iters, int(np.ceil(np.log(1.0 - confidence) / denom))) if denom < 0 else it
-    return best_mask
+def _lattice_case(rng, trial):
+    """Matched keypoint pairs as FeatureRegistrator meets them: integer pixel positions, a similarity (every third trial a pure
+    integer translation, under which residuals of EXACTLY the 3-px threshold occur) plus noise, a share of outliers."""
+    n = int(rng.integers(5, 2500))
+    th, sc = rng.uniform(-0.05, 0.05), rng.uniform(0.95, 1.05)
+    M = np.array([[sc * np.cos(th), -sc * np.sin(th), float(rng.integers(-30, 30))],
+                  [sc * np.sin(th), sc * np.cos(th), float(rng.integers(-30, 30))]])
+    if trial % 3 == 0:
+        M = np.array([[1, 0, float(rng.integers(-30, 30))], [0, 1, float(rng.integers(-30, 30))]], float)
+    src = rng.integers(0, 1500, (n, 2)).astype(np.float32)
+    dst = np.rint(src @ M[:, :2].T + M[:, 2] + rng.normal(0, 1.2, (n, 2))).astype(np.float32)
+    out = rng.random(n) < rng.uniform(0, 0.6)
+    dst[out] = rng.integers(0, 1500, (int(out.sum()), 2)).astype(np.float32)
+    return src, dst
 
 
-def test_ransac_sampling_loop_equals_its_least_squares_statement_on_pixel_lattices():
-    """Keypoints are integer pixel positions, so residuals of EXACTLY the threshold (3 px) occur -- under a pure translation in
-    particular -- and a two-point model that differs in the last bit flips them.  The closed-form sample fits of round 5 must
-    select the very inlier sets the least-squares fits select (hence the same final matrix)."""
+def test_similarity_fit_is_the_least_squares_solution():
+    """sparse_cpu._fit_similarity (closed form from centred integer sums, float64) against the same minimisation solved
+    EXACTLY -- the normal equations of the uncentred problem in rational arithmetic -- and, loosely, against numpy's SVD-based
+    lstsq on the 2n x 4 design matrix (which loses digits itself when the points sit far from the origin)."""
+    from fractions import Fraction as F
+    rng = np.random.default_rng(2)
+    for trial in range(40):
+        src, dst = _lattice_case(rng, trial)
+        src, dst = src.astype(np.float64) + (4000 if trial % 5 == 0 else 0), dst.astype(np.float64)
+        n = len(src)
+        x, y, u, v = ([int(t) for t in col] for col in (src[:, 0], src[:, 1], dst[:, 0], dst[:, 1]))
+        Sx, Sy, Su, Sv = sum(x), sum(y), sum(u), sum(v)
+        Sxx = sum(p * p + q * q for p, q in zip(x, y))
+        Sxu = sum(p * r + q * t for p, q, r, t in zip(x, y, u, v))
+        Sxv = sum(p * t - q * r for p, q, r, t in zip(x, y, u, v))
+        D = F(n * Sxx - (Sx * Sx + Sy * Sy))
+        a, b = (n * Sxu - (Sx * Su + Sy * Sv)) / D, (n * Sxv - (Sx * Sv - Sy * Su)) / D
+        tx, ty = (Su - (a * Sx - b * Sy)) / n, (Sv - (b * Sx + a * Sy)) / n
+        exact = np.array([[float(a), float(-b), float(tx)], [float(b), float(a), float(ty)]])
+        M = SP._fit_similarity(src, dst)
+        assert np.allclose(M, exact, rtol=1e-13, atol=1e-12), (trial, np.abs(M - exact).max())
+        A = np.zeros((2 * n, 4))
+        A[0::2, 0], A[0::2, 1], A[0::2, 2] = src[:, 0], -src[:, 1], 1.0
+        A[1::2, 0], A[1::2, 1], A[1::2, 3] = src[:, 1], src[:, 0], 1.0
+        la, lb, ltx, lty = np.linalg.lstsq(A, dst.reshape(-1), rcond=None)[0]
+        assert np.allclose(M, [[la, -lb, ltx], [lb, la, lty]], rtol=0, atol=1e-7), trial
+    assert SP._fit_similarity(np.ones((5, 2)), rng.random((5, 2))) is None           # coinciding source points: rank < 4
+    assert SP._fit_similarity(np.ones((1, 2)), np.ones((1, 2))) is None
+
+
+def test_random_stream_of_the_device_ransac_is_numpys():
+    """csrc/ransac.hip restates numpy's PCG64 stream, its Lemire bounded integers and Generator.choice(n, 2, replace=False)
+    on the host side of ma_match_similarity: the very pairs numpy draws, for populations from 2 to 2^31; and its adaptive
+    iteration count is sparse_cpu.ransac_iterations (both the C library's log)."""
+    import ctypes as C
+    from microaligner_amd import _lib as L
+    lib = L.load()
+    for seed in (0, 7):
+        raw = np.random.PCG64(seed).state["state"]
+        m64 = (1 << 64) - 1
+        st = (C.c_ulonglong * 4)(raw["state"] >> 64, raw["state"] & m64, raw["inc"] >> 64, raw["inc"] & m64)
+        for n in (2, 3, 4, 5, 7, 100, 4097, 45000, 65536, 1000003, 2 ** 31 - 5):
+            cnt = 2000 if n < 100000 else 200
+            out = np.zeros((cnt, 2), np.int32)
+            L.check(lib.ma_host_pcg64_choice2(st, n, cnt, out.ctypes.data_as(C.POINTER(C.c_int))))
+            rng = np.random.default_rng(seed)
+            assert np.array_equal(out, np.array([rng.choice(n, 2, replace=False) for _ in range(cnt)])), (seed, n)
+    rng = np.random.default_rng(3)
+    for _ in range(3000):
+        n = int(rng.integers(2, 50000))
+        count = int(rng.integers(0, n + 1))
+        it = int(rng.integers(1, 2000))
+        conf = float(rng.choice([0.99, 0.9, 0.999, rng.uniform(0.5, 0.9999)]))
+        got = C.c_int(-1)
+        L.check(lib.ma_host_ransac_iterations(count, n, conf, 2000, it, C.byref(got)))
+        assert got.value == SP.ransac_iterations(count, n, conf, 2000, it), (count, n, conf, it)
+
+
+@pytest.mark.gpu
+def test_device_ratio_test_and_ransac_equal_the_host_statement(ctx):
+    """ma_match_similarity against sparse_cpu.estimate_affine_partial_2d over the good matches, bit for bit: the same matrix
+    (array_equal), the same number of good matches, None where the host returns None -- on pixel lattices with exact-threshold
+    residuals, with outliers, duplicated points, and with too few matches."""
     rng = np.random.default_rng(1)
-    for trial in range(120):
-        n = int(rng.integers(5, 2500))
-        th, sc = rng.uniform(-0.05, 0.05), rng.uniform(0.95, 1.05)
-        M = np.array([[sc * np.cos(th), -sc * np.sin(th), float(rng.integers(-30, 30))],
-                      [sc * np.sin(th), sc * np.cos(th), float(rng.integers(-30, 30))]])
-        if trial % 3 == 0:
-            M = np.array([[1, 0, float(rng.integers(-30, 30))], [0, 1, float(rng.integers(-30, 30))]], float)
-        src = rng.integers(0, 1500, (n, 2)).astype(np.float32)
-        dst = np.rint(src @ M[:, :2].T + M[:, 2] + rng.normal(0, 1.2, (n, 2))).astype(np.float32)
-        out = rng.random(n) < rng.uniform(0, 0.6)
-        dst[out] = rng.integers(0, 1500, (int(out.sum()), 2)).astype(np.float32)
-        est, mask = SP.estimate_affine_partial_2d(src, dst)
-        ref_mask = _ransac_by_least_squares(src, dst)
-        if est is None:
-            assert ref_mask is None or ref_mask.sum() < 2
+    for trial in range(150):
+        mov, ref = _lattice_case(rng, trial)                 # query (moving) points and where each one's match lies
+        nq = len(mov)
+        if trial % 10 == 4:
+            mov[: nq // 2] = mov[0]                          # many coinciding points: degenerate samples
+        if trial % 10 == 7:
+            mov, ref = mov[:4], ref[:4]
+            nq = 4
+        # train set: the matched points shuffled among decoys; the search result: nearest = the match, second = anything
+        nt = nq + int(rng.integers(0, 300))
+        perm = rng.permutation(nt)[:nq]
+        train = rng.integers(0, 1500, (nt, 2)).astype(np.float64)
+        train[perm] = ref
+        idx = np.stack([perm, rng.integers(0, nt, nq)], 1).astype(np.int32)
+        d1 = rng.uniform(0.5, 2.0, nq).astype(np.float32)
+        good_share = rng.uniform(0.0, 1.0) if trial % 6 else 0.002
+        d0 = np.where(rng.random(nq) < good_share, d1 * rng.uniform(0.01, 0.2499, nq), d1 * rng.uniform(0.2501, 1.0, nq)).astype(np.float32)
+        if trial % 4 == 1:
+            d0[::7] = (d1[::7] * np.float32(0.25))           # sqrt(d0) == 0.5 sqrt(d1) up to float32 rounding: the strict test
+        dist_sq = np.stack([d0, d1], 1).astype(np.float32)
+        dist = np.sqrt(dist_sq)
+        good = np.nonzero(dist[:, 0] < 0.5 * dist[:, 1])[0]
+        mat, n_good, status = ctx.match_similarity(ctx._upload_raw(idx), ctx._upload_raw(dist_sq),
+                                                   ctx._upload_raw(mov.astype(np.float64)), ctx._upload_raw(train))
+        assert n_good == len(good), trial
+        if len(good) < 3:
+            assert status == 1 and mat is None
             continue
-        # the final matrix is the (iterated) least-squares fit on the selected inliers: equal selections, equal matrices
-        M2 = SP._fit_similarity(src.astype(np.float64)[ref_mask], dst.astype(np.float64)[ref_mask])
-        for _ in range(10):
-            m = ((src.astype(np.float64) @ M2[:, :2].T + M2[:, 2] - dst) ** 2).sum(1) < 9.0
-            if m.sum() < 2 or np.array_equal(m, ref_mask):
-                break
-            ref_mask = m
-            nxt = SP._fit_similarity(src.astype(np.float64)[m], dst.astype(np.float64)[m])
-            if nxt is None:
-                break
-            M2 = nxt
-        assert np.array_equal(mask, ref_mask) and np.array_equal(est, M2), trial
+        exp, _ = SP.estimate_affine_partial_2d(mov[good], train[idx[good, 0]].astype(np.float32))
+        if exp is None:
+            assert status == 2 and mat is None, trial
+        else:
+            assert status == 0 and np.array_equal(mat, exp), (trial, mat, exp)
+    # coordinates that are not integer-valued are left to the host statement
+    mov = rng.random((50, 2)) * 100
+    idx = np.stack([np.arange(50), np.arange(50)[::-1]], 1).astype(np.int32)
+    dist_sq = np.stack([np.full(50, 0.01), np.ones(50)], 1).astype(np.float32)
+    mat, n_good, status = ctx.match_similarity(ctx._upload_raw(idx), ctx._upload_raw(dist_sq), ctx._upload_raw(mov),
+                                               ctx._upload_raw(mov + 3.0))
+    assert (mat, n_good, status) == (None, 50, 3)
 
 
 @pytest.mark.gpu

@@ -888,3 +888,48 @@ def test_results_land_by_dma_in_caller_memory_that_was_page_locked_in_place(ctx,
     gc.collect()
     # memory that cannot be registered is reported, not raised
     assert device.host_register(np.empty(0, np.float32)) is False
+
+
+def test_a_copy_that_runs_past_a_page_locked_range_is_staged(ctx):
+    """is_page_locked (csrc/ma_api.hip) decides per TRANSFER, not per start pointer: a range that begins inside a registered row
+    (or inside a hipHostMalloc buffer) and ends beyond it is partly pageable and must take the staging ring; the bytes arrive
+    either way.  parallel.shared_array registers row by row in multi-rank runs, so `arr[r:r + 2]` with only row r registered
+    is exactly this case."""
+    import ctypes as C
+    from microaligner_amd import device
+    from microaligner_amd import _lib as L
+    lib = L.load()
+
+    def direct(ptr, nbytes):
+        out = C.c_int(-1)
+        L.check(lib.ma_host_transfer_is_direct(C.c_void_p(ptr), C.c_size_t(nbytes), C.byref(out)))
+        return out.value
+
+    rng = np.random.default_rng(9)
+    rows = np.empty((3, 1024, 2048), np.float32)                 # 8 MB per row: above the staging threshold
+    row_bytes = rows[0].nbytes
+    base = rows.ctypes.data
+    assert direct(base, row_bytes) == 0                          # pageable
+    assert lib.ma_host_register(C.c_void_p(base + row_bytes), C.c_size_t(row_bytes)) == L.MA_OK      # row 1 only
+    try:
+        assert direct(base + row_bytes, row_bytes) == 1
+        assert direct(base + row_bytes + 4096, row_bytes - 4096) == 1
+        assert direct(base + row_bytes, row_bytes + 1) == 0      # starts inside, ends one byte past the registration
+        assert direct(base + row_bytes, 2 * row_bytes) == 0
+        assert direct(base, 2 * row_bytes) == 0                  # starts before it
+        src = rng.random((2, 1024, 2048)).astype(np.float32)
+        dev = ctx.asdevice(src)
+        dev.numpy(out=rows[1:3])                                 # download across the end of the registered row
+        assert np.array_equal(rows[1:3], src)
+        assert np.array_equal(ctx.asdevice(rows[1:3].copy()).numpy(), src)
+        up = ctx.empty(src.shape, np.float32)                    # upload FROM the overrunning range
+        L.check(lib.ma_memcpy_h2d(ctx.handle, up.ptr, C.c_void_p(base + row_bytes), C.c_size_t(2 * row_bytes)))
+        assert np.array_equal(up.numpy(), src)
+    finally:
+        assert lib.ma_host_unregister(C.c_void_p(base + row_bytes)) == L.MA_OK
+    assert direct(base + row_bytes, row_bytes) == 0
+    # the runtime's own page-locked allocations: whole buffer direct, a range past its end not
+    pinned = ctx.host_empty((1024, 2048), np.float32)
+    assert direct(pinned.ctypes.data, pinned.nbytes) == 1
+    assert direct(pinned.ctypes.data, 64 << 20) == 0
+    del pinned
