@@ -422,6 +422,16 @@ int ma_fast_keypoints(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int marg
  * (n_tiles, P, P). */
 int ma_cut_tiles_u8(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int first_tile, int n_tiles,
                     uint8_t* tiles_out);
+/* find_features of a whole uint8 device image in one call (tile_registration.py:78-97 -> feature_detection.py:88-120,
+ * 161-168): the feature windows are cut (ma_cut_tiles_u8), the corners detected, ranked and cut to `limit` per tile
+ * (ma_fast_keypoints), compacted tile by tile in combine_features' order (tiles with fewer than 3 keypoints dropped) and
+ * described (ma_daisy_describe, the smoothing limited to each window's image content) -- everything stays on the device, in
+ * batches of tiles sized from workspace_bytes (0: 8 GiB); only the number of keypoints comes back (one synchronisation).
+ * desc_out: (capacity, 200) float32, pts_out: (capacity, 2) float64 (x, y) in image coordinates, resp_out: (capacity) int32
+ * responses, all device; capacity >= tiles x limit.  Tables as for ma_daisy_describe. */
+int ma_feature_extract(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int threshold, int limit,
+                       const double* const* weights_host, const int* radii, const double* cos_sin_host, const double* offs_host,
+                       size_t workspace_bytes, int capacity, float* desc_out, double* pts_out, int* resp_out, int* n_out_host);
 /* ma_daisy_describe: DAISY descriptors (radius 21, 3 rings x 8 locations + centre, 8 orientation bins = 200 floats,
  * no normalisation, bilinear sampling; feature_detection.py:107-110) at nkp keypoints.  tiles: (nt, P, P) uint8 or
  * float32 (device).  weights_host[c] / radii[c]: centre-first half of the c-th incremental Gaussian kernel (host

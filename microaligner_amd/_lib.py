@@ -82,6 +82,8 @@ SIGNATURES = {
     "ma_host_pcg64_choice2": (_i, [C.POINTER(C.c_ulonglong), _i, _i, C.POINTER(_i)]),
     "ma_host_ransac_iterations": (_i, [_i, _i, _d, _i, _i, C.POINTER(_i)]),
     "ma_fast_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "ma_feature_extract": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.POINTER(_d)), C.POINTER(_i), C.POINTER(_d),
+                                C.POINTER(_d), _sz, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     "ma_daisy_describe": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.POINTER(_d)), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d),
                                _vp, _vp, _i, _vp]),
 }

@@ -69,10 +69,15 @@ __global__ __launch_bounds__(256) void fast_nms_kernel(const int* __restrict__ s
 // products and the sum in float64 (numpy promotes: the cosines are float64 scalars).
 template <typename T>
 __global__ __launch_bounds__(256) void daisy_layers_kernel(const T* __restrict__ tiles, int P, const double* __restrict__ cs,
-                                                           float* __restrict__ layers)
+                                                           float* __restrict__ layers, const int4* __restrict__ rects)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, t = blockIdx.z;
-    if (x >= P) return;
+    // the layers are made where they can be non-zero: the content rectangle and one pixel around it (see DzRect below)
+    const int t = blockIdx.z;
+    const int4 c = rects[t];                               // y0, y1, x0, x1
+    if (c.y <= c.x || c.w <= c.z) return;
+    const int vy0 = max(c.x - 1, 0), vy1 = min(c.y + 1, P), vx0 = max(c.z - 1, 0), vx1 = min(c.w + 1, P);
+    const int x = vx0 + blockIdx.x * 256 + threadIdx.x, y = vy0 + blockIdx.y;
+    if (x >= vx1 || y >= vy1) return;
     const T* img = tiles + (size_t)t * P * P;
     auto f = [&](int yy, int xx) -> float {
         const float v = (float)img[(size_t)yy * P + xx];
@@ -110,39 +115,78 @@ __global__ __launch_bounds__(256) void smooth_axis_kernel(const float* __restric
     dst[(size_t)blockIdx.z * P * P + (size_t)y * P + x] = (float)acc;
 }
 
-// The same filter for radii up to RB with the window of a thread in registers: the plane is read as [A][B] (B contiguous,
-// one thread per b), filtered along A for NY consecutive outputs per thread -- every input row is loaded and converted
-// once for up to NY outputs instead of once per tap -- and written TRANSPOSED, [B][A], through LDS.
-// Two launches make scipy's two passes: y then x, the second one reading the transposed intermediate and transposing it
-// back.  Per output the arithmetic is that of smooth_axis_kernel, tap for tap: acc = x[0] w[0]; acc += (x[-j] + x[+j]) w[j],
-// j = r .. 1.  Taps beyond r are skipped by a uniform branch (their rows are loaded all the same: clamped addresses).
+// ---- content rectangles -------------------------------------------------------------------------------------------------
+// A feature tile is a window of the image, ZERO outside it (slicer.py:69-118): of the 3 x 3 windows of a 2048^2 level at
+// tile size 1000, five hold a strip of 48 + 51 image pixels and 1000 columns of zeros.  Where the tile is zero the
+// orientation layers are zero, and a smoothed cube is zero beyond the reach of its kernels, so every kernel below works on
+// the tile's CONTENT rectangle dilated by the halo its stage has accumulated (1 px for the gradient, + the radius of every
+// smoothing pass so far) and treats what lies outside as the zeros it holds -- without reading or writing them.  Values are
+// those of the full computation (the sign of a zero can differ: -0.0 where the full computation multiplies a zero gradient
+// by a negative cosine; IEEE comparisons and every later sum do not see it).  rect = {y0, y1, x0, x1} of the content in tile
+// coordinates, y1 <= y0 for an empty tile; the plain entry point passes the whole tile.
+struct DzRect { int y0, y1, x0, x1; };
+
+__device__ __forceinline__ DzRect dz_dilate(const DzRect c, int hy, int hx, int P)
+{
+    DzRect v;
+    v.y0 = max(c.y0 - hy, 0); v.y1 = min(c.y1 + hy, P);
+    v.x0 = max(c.x0 - hx, 0); v.x1 = min(c.x1 + hx, P);
+    if (c.y1 <= c.y0 || c.x1 <= c.x0) { v.y0 = v.y1 = v.x0 = v.x1 = 0; }
+    return v;
+}
+
+// The smoothing filter with the window of a thread in registers, sliding: the plane is read as [A][B] (B contiguous, one
+// thread per b), filtered along A for NY * NIT consecutive outputs per thread -- the window of NY + 2 RB inputs moves down by
+// NY rows per step, so every input row is loaded and converted ONCE per thread, and the rows of the next step are in flight
+// while this step's taps are applied -- and written TRANSPOSED, [B][A], through LDS.  Two launches make scipy's two passes:
+// y then x, the second one reading the transposed intermediate and transposing it back.  Per output the arithmetic is that
+// of smooth_axis_kernel, tap for tap: acc = x[0] w[0]; acc += (x[-j] + x[+j]) w[j], j = r .. 1.  Taps beyond r are skipped
+// by a uniform branch.
+// Geometry per plane (tile = plane / 8): the input holds values for a in [ia0, ia1), b in [b0, b1) -- the content rectangle
+// dilated by (h_a, h_b) -- and zeros elsewhere; outputs are made for a in [ia0 - r, ia1 + r) within the plane.  swap: 0 when
+// a runs along y (first pass), 1 when a runs along x (second pass, transposed input).
 constexpr int ST_B = 64;      // one wave per block: 64 columns b
 
 template <int RB, int NY, int NIT>
-__global__ __launch_bounds__(ST_B) void smooth_transposing_kernel(const float* __restrict__ src, int A, int B,
-                                                                  const double* __restrict__ w, int r, float* __restrict__ dst)
+__global__ __launch_bounds__(ST_B) void smooth_slide_kernel(const float* __restrict__ src, int A, int B,
+                                                            const double* __restrict__ w, int r, float* __restrict__ dst,
+                                                            const DzRect* __restrict__ rects, int h_a, int h_b, int swap)
 {
-    // the wave's outputs, [b][a] with a odd pitch: written a column of NY per thread, read back a row of 64 per store,
-    // so that the transposed plane is written in runs of 256 contiguous bytes and not in pieces of a thread's 64
-    constexpr int NA = NY * NIT, TP = NA + 1;
+    constexpr int NA = NY * NIT, TP = NA + 1, WN = NY + 2 * RB;
     __shared__ float tile[ST_B * TP];
-    const int lane = threadIdx.x, b0 = blockIdx.x * ST_B, a00 = blockIdx.y * NA;
-    const int b = min(b0 + lane, B - 1);         // lanes past the edge compute a copy of the last column and store nothing
+    const int lane = threadIdx.x;
+    DzRect c = rects[blockIdx.z >> 3];
+    if (swap) { DzRect t = c; c.y0 = t.x0; c.y1 = t.x1; c.x0 = t.y0; c.x1 = t.y1; }
+    const DzRect vin = dz_dilate(c, h_a, h_b, A);          // A == B == P
+    const int ia0 = vin.y0, ia1 = vin.y1, b0 = vin.x0 + blockIdx.x * ST_B, b1 = vin.x1;
+    const int oa0 = max(ia0 - r, 0), oa1 = min(ia1 + r, A);
+    const int a00 = oa0 + blockIdx.y * NA;
+    if (b0 >= b1 || a00 >= oa1 || ia1 <= ia0) return;      // uniform: nothing of this plane in the block
+    const int b = min(b0 + lane, b1 - 1);                  // lanes past the edge compute a copy of the last column and store nothing
     const float* s = src + (size_t)blockIdx.z * A * B + b;
+    auto row = [&](int a) -> float {                       // input row a of this thread's column: clamped like scipy's
+        const int ac = d_clamp(a, 0, A - 1);               // mode="nearest", zero outside the rows that hold values
+        const float v = s[(size_t)d_clamp(ac, ia0, ia1 - 1) * B];
+        return (ac >= ia0 && ac < ia1) ? v : 0.f;
+    };
     double wv[RB + 1];
 #pragma unroll
-    for (int j = 0; j <= RB; j++) wv[j] = w[j];        // the table is padded: entries beyond r exist and are not used
+    for (int j = 0; j <= RB; j++) wv[j] = w[j];            // the table is padded: entries beyond r exist and are not used
+    double win[WN];
+#pragma unroll
+    for (int i = 0; i < 2 * RB; i++) win[i] = (double)row(a00 - RB + i);
+    float nxt[NY];
+#pragma unroll
+    for (int i = 0; i < NY; i++) nxt[i] = row(a00 + RB + i);
     for (int it = 0; it < NIT; it++) {
         const int a0 = a00 + it * NY;
-        if (a0 >= A) break;
-        // every row of the window is loaded (clamped addresses are always valid) before anything is used: one batch of
-        // loads in flight instead of a round trip per row
-        float raw[NY + 2 * RB];
+        if (a0 >= oa1) break;
 #pragma unroll
-        for (int i = 0; i < NY + 2 * RB; i++) raw[i] = s[(size_t)d_clamp(a0 + i - RB, 0, A - 1) * B];
-        double win[NY + 2 * RB];
+        for (int i = 0; i < NY; i++) win[2 * RB + i] = (double)nxt[i];
+        if (it + 1 < NIT) {                                // the next step's rows: in flight during this step's arithmetic
 #pragma unroll
-        for (int i = 0; i < NY + 2 * RB; i++) win[i] = (double)raw[i];
+            for (int i = 0; i < NY; i++) nxt[i] = row(a0 + NY + RB + i);
+        }
         double acc[NY];
 #pragma unroll
         for (int o = 0; o < NY; o++) acc[o] = __dmul_rn(win[o + RB], wv[0]);
@@ -156,36 +200,74 @@ __global__ __launch_bounds__(ST_B) void smooth_transposing_kernel(const float* _
         }
 #pragma unroll
         for (int o = 0; o < NY; o++) tile[lane * TP + it * NY + o] = (float)acc[o];
+#pragma unroll
+        for (int i = 0; i < 2 * RB; i++) win[i] = win[i + NY];
     }
     __syncthreads();
     float* d = dst + (size_t)blockIdx.z * A * B + a00;
-    const int nb = min(ST_B, B - b0);
+    const int nb = min(ST_B, b1 - b0);
     for (int a = lane; a < NA; a += 64) {
-        if (a00 + a < A) {
+        if (a00 + a < oa1) {
             for (int bb = 0; bb < nb; bb++) d[(size_t)(b0 + bb) * A + a] = tile[bb * TP + a];
         }
     }
 }
 
-// one smoothing pass pair (y, then x) of `planes` planes of P x P: src -> mid (transposed) -> dst
-template <int RB, int NY, int NIT>
-static void smooth_pair(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r)
+// smooth_axis_kernel with the same geometry (any radius: a thread per output, every tap from memory)
+template <bool ALONG_X>
+__global__ __launch_bounds__(256) void smooth_axis_rect_kernel(const float* __restrict__ src, int P, const double* __restrict__ w,
+                                                               int r, float* __restrict__ dst, const DzRect* __restrict__ rects,
+                                                               int h_y, int h_x)
 {
-    const dim3 grid((P + ST_B - 1) / ST_B, (P + NY * NIT - 1) / (NY * NIT), planes);
-    hipLaunchKernelGGL((smooth_transposing_kernel<RB, NY, NIT>), grid, dim3(ST_B), 0, stream, src, P, P, w, r, mid);
-    hipLaunchKernelGGL((smooth_transposing_kernel<RB, NY, NIT>), grid, dim3(ST_B), 0, stream, (const float*)mid, P, P, w, r, dst);
+    const DzRect vin = dz_dilate(rects[blockIdx.z >> 3], h_y, h_x, P);
+    DzRect vo = vin;
+    if (ALONG_X) { vo.x0 = max(vin.x0 - r, 0); vo.x1 = min(vin.x1 + r, P); }
+    else { vo.y0 = max(vin.y0 - r, 0); vo.y1 = min(vin.y1 + r, P); }
+    const int x = vo.x0 + blockIdx.x * 256 + threadIdx.x, y = vo.y0 + blockIdx.y;
+    if (x >= vo.x1 || y >= vo.y1 || vin.y1 <= vin.y0) return;
+    const float* s = src + (size_t)blockIdx.z * P * P;
+    auto at = [&](int d) -> double {
+        const int yy = ALONG_X ? y : d_clamp(y + d, 0, P - 1), xx = ALONG_X ? d_clamp(x + d, 0, P - 1) : x;
+        if (yy < vin.y0 || yy >= vin.y1 || xx < vin.x0 || xx >= vin.x1) return 0.0;
+        return (double)s[(size_t)yy * P + xx];
+    };
+    double acc = __dmul_rn(at(0), w[0]);
+    for (int j = r; j >= 1; j--) acc = __dadd_rn(acc, __dmul_rn(__dadd_rn(at(-j), at(j)), w[j]));
+    dst[(size_t)blockIdx.z * P * P + (size_t)y * P + x] = (float)acc;
 }
 
-static void smooth_planes(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r)
+// extent of the rectangles the launches below have to cover (host side: the rects are known there)
+struct DzSpan { int h, w; };      // the largest content height / width over the tiles of the batch
+
+// one smoothing pass pair (y, then x) of `planes` planes of P x P: src -> mid (transposed) -> dst.  h: halo the input has
+// accumulated; span: largest content extent.
+template <int RB, int NY, int NIT>
+static void smooth_pair(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r,
+                        const DzRect* rects, int h, DzSpan span)
 {
-    if (r <= 12) smooth_pair<12, 16, 4>(stream, src, mid, dst, P, planes, w, r);
-    else if (r <= 18) smooth_pair<18, 16, 4>(stream, src, mid, dst, P, planes, w, r);
-    else if (r <= 24) smooth_pair<24, 16, 4>(stream, src, mid, dst, P, planes, w, r);
-    else if (r <= 40) smooth_pair<40, 8, 8>(stream, src, mid, dst, P, planes, w, r);
+    constexpr int NA = NY * NIT;
+    const int in_h = std::min(P, span.h + 2 * h), in_w = std::min(P, span.w + 2 * h);
+    const int out_h = std::min(P, in_h + 2 * r), out_w = std::min(P, in_w + 2 * r);
+    // pass 1: a = y (outputs out_h), b = x (in_w columns); pass 2: a = x (outputs out_w), b = y (out_h columns)
+    const dim3 g1((in_w + ST_B - 1) / ST_B, (out_h + NA - 1) / NA, planes), g2((out_h + ST_B - 1) / ST_B, (out_w + NA - 1) / NA, planes);
+    hipLaunchKernelGGL((smooth_slide_kernel<RB, NY, NIT>), g1, dim3(ST_B), 0, stream, src, P, P, w, r, mid, rects, h, h, 0);
+    hipLaunchKernelGGL((smooth_slide_kernel<RB, NY, NIT>), g2, dim3(ST_B), 0, stream, (const float*)mid, P, P, w, r, dst, rects, h, h + r, 1);
+}
+
+static void smooth_planes(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r,
+                          const DzRect* rects, int h, DzSpan span)
+{
+    if (r <= 12) smooth_pair<12, 16, 4>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
+    else if (r <= 18) smooth_pair<18, 16, 4>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
+    else if (r <= 24) smooth_pair<24, 16, 4>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
+    else if (r <= 40) smooth_pair<40, 8, 8>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
     else {   // any radius: a thread per output, every tap from memory
-        const dim3 pgrid((P + 255) / 256, P, planes);
-        hipLaunchKernelGGL((smooth_axis_kernel<false>), pgrid, dim3(256), 0, stream, src, P, w, r, mid);
-        hipLaunchKernelGGL((smooth_axis_kernel<true>), pgrid, dim3(256), 0, stream, (const float*)mid, P, w, r, dst);
+        const int in_h = std::min(P, span.h + 2 * h), in_w = std::min(P, span.w + 2 * h);
+        const int out_h = std::min(P, in_h + 2 * r), out_w = std::min(P, in_w + 2 * r);
+        hipLaunchKernelGGL((smooth_axis_rect_kernel<false>), dim3((in_w + 255) / 256, out_h, planes), dim3(256), 0, stream, src, P, w,
+                           r, mid, rects, h, h);
+        hipLaunchKernelGGL((smooth_axis_rect_kernel<true>), dim3((out_w + 255) / 256, out_h, planes), dim3(256), 0, stream,
+                           (const float*)mid, P, w, r, dst, rects, h + r, h);
     }
 }
 
@@ -194,9 +276,15 @@ static void smooth_planes(hipStream_t stream, const float* src, float* mid, floa
 // (float64 offsets computed by the host with numpy); bilinear weights and the blend in float32, left to right.
 __global__ __launch_bounds__(256) void daisy_sample_kernel(const float* __restrict__ cubes, size_t cube_stride, int P,
                                                            const int* __restrict__ kp_tile, const double* __restrict__ kp_xy,
-                                                           const double* __restrict__ offs, int nkp, float* __restrict__ desc)
+                                                           const double* __restrict__ offs, int nkp, const int* __restrict__ nkp_dev,
+                                                           float* __restrict__ desc, const DzRect* __restrict__ rects, int h0,
+                                                           int h1, int h2)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
+    // ma_feature_extract: nkp_dev[0] = the count the selection left on the device, nkp_dev[1] = descriptors of the batches
+    // before this one (the slot of keypoint 0 in desc)
+    size_t slot0 = 0;
+    if (nkp_dev) { nkp = min(nkp, nkp_dev[0]); slot0 = (size_t)nkp_dev[1]; }
     if (e >= nkp * 25) return;
     const int k = e / 25, loc = e - k * 25;
     const int cube = loc == 0 ? 0 : (loc - 1) / 8;
@@ -208,12 +296,20 @@ __global__ __launch_bounds__(256) void daisy_sample_kernel(const float* __restri
     const float fy = (float)(ys - (double)y0), fx = (float)(xs - (double)x0);
     const long long y1 = y0 + 1 < P - 1 ? y0 + 1 : P - 1, x1 = x0 + 1 < P - 1 ? x0 + 1 : P - 1;
     const float w00 = (1.f - fy) * (1.f - fx), w01 = (1.f - fy) * fx, w10 = fy * (1.f - fx), w11 = fy * fx;
-    const float* base = cubes + cube * cube_stride + (size_t)kp_tile[k] * 8 * P * P;
-    float* out = desc + (size_t)k * 200 + loc * 8;
+    const int t = kp_tile[k];
+    // the cube holds values inside the content rectangle dilated by its accumulated halo and is zero (unwritten) outside
+    const int h = cube == 0 ? h0 : (cube == 1 ? h1 : h2);
+    const DzRect v = dz_dilate(rects[t], h, h, P);
+    const bool iy0 = y0 >= v.y0 && y0 < v.y1, iy1 = y1 >= v.y0 && y1 < v.y1, ix0 = x0 >= v.x0 && x0 < v.x1,
+               ix1 = x1 >= v.x0 && x1 < v.x1;
+    const float* base = cubes + cube * cube_stride + (size_t)t * 8 * P * P;
+    float* out = desc + (slot0 + k) * 200 + loc * 8;
 #pragma unroll
     for (int o = 0; o < 8; o++) {
         const float* pl = base + (size_t)o * P * P;
-        out[o] = pl[y0 * P + x0] * w00 + pl[y0 * P + x1] * w01 + pl[y1 * P + x0] * w10 + pl[y1 * P + x1] * w11;
+        const float v00 = iy0 && ix0 ? pl[y0 * P + x0] : 0.f, v01 = iy0 && ix1 ? pl[y0 * P + x1] : 0.f;
+        const float v10 = iy1 && ix0 ? pl[y1 * P + x0] : 0.f, v11 = iy1 && ix1 ? pl[y1 * P + x1] : 0.f;
+        out[o] = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
     }
 }
 
@@ -405,6 +501,167 @@ __global__ __launch_bounds__(KS_T) void kp_sort_kernel(const unsigned long long*
     if (tid == 0) counts[t] = n_sel;
 }
 
+
+// ---- the selection's keypoints, compacted on the device (combine_features' layout, tile_registration.py:37-74) --------------
+// base[t] = number of keypoints of the batch's tiles before t that stay (tiles with fewer than three are dropped,
+// feature_detection.py:112-115); info[0] = keypoints of the batch, info[1] = keypoints of the batches before it; *total grows
+__global__ void kp_offsets_kernel(const int* __restrict__ counts, int nt, int* __restrict__ base, int* __restrict__ info,
+                                  int* __restrict__ total)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    int run = 0;
+    for (int t = 0; t < nt; t++) {
+        base[t] = run;
+        run += counts[t] >= 3 ? counts[t] : 0;
+    }
+    info[0] = run;
+    info[1] = *total;
+    *total += run;
+}
+
+// keypoint k of tile t -> slot base[t] + k of the batch: its tile and tile coordinates for the descriptor, and -- at the
+// level-wide slot info[1] + base[t] + k -- its image coordinates (tile origin + interior coordinate) and response
+__global__ __launch_bounds__(256) void kp_compact_kernel(const int* __restrict__ kp, const int* __restrict__ counts,
+                                                         const int* __restrict__ base, const int* __restrict__ info, int limit,
+                                                         int tile_size, int ntx, int first_tile, int* __restrict__ kp_tile,
+                                                         double* __restrict__ kp_xy, double* __restrict__ pts_out,
+                                                         int* __restrict__ resp_out)
+{
+    const int t = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x, c = counts[t];
+    if (c < 3 || k >= c) return;
+    const int* e = kp + ((size_t)t * limit + k) * 3;
+    const int o = base[t] + k, tile = first_tile + t;
+    kp_tile[o] = t;
+    kp_xy[2 * o] = (double)e[0];
+    kp_xy[2 * o + 1] = (double)e[1];
+    const size_t g = (size_t)info[1] + o;
+    pts_out[2 * g] = (double)e[0] + (double)((tile % ntx) * tile_size);
+    pts_out[2 * g + 1] = (double)e[1] + (double)((tile / ntx) * tile_size);
+    resp_out[g] = e[2];
+}
+
+} // namespace
+
+// ---- host side ----------------------------------------------------------------------------------------------------------
+namespace {
+
+// scratch of the detector + selection for nt tiles of interior Pi, laid out in one buffer
+struct FastScratch {
+    size_t npx, map, bytes;
+    int nch;
+    int *raw, *nms, *chunk_hist, *tile_hist, *chunk_base, *cut;
+    unsigned long long* keys;
+    static size_t size(int nt, int Pi, int& nch_out)
+    {
+        const size_t npx = (size_t)Pi * Pi, map = (size_t)nt * npx * sizeof(int);
+        nch_out = (int)((npx + KC_CH - 1) / KC_CH);
+        const size_t b_ch = (size_t)nt * nch_out * 256 * sizeof(int), b_keys = (size_t)nt * KS_CAP * sizeof(unsigned long long),
+                     b_th = (size_t)nt * 256 * sizeof(int), b_cb = (size_t)nt * nch_out * 2 * sizeof(int),
+                     b_cut = (size_t)nt * 4 * sizeof(int);
+        return ma_align_up(2 * map, 8) + b_keys + b_ch + b_th + b_cb + b_cut + 64;
+    }
+    void place(void* buf, int nt, int Pi)
+    {
+        npx = (size_t)Pi * Pi; map = (size_t)nt * npx * sizeof(int);
+        bytes = size(nt, Pi, nch);
+        raw = (int*)buf;
+        nms = raw + (size_t)nt * npx;
+        keys = (unsigned long long*)((char*)buf + ma_align_up(2 * map, 8));
+        chunk_hist = (int*)(keys + (size_t)nt * KS_CAP);
+        tile_hist = chunk_hist + (size_t)nt * nch * 256;
+        chunk_base = tile_hist + (size_t)nt * 256;
+        cut = chunk_base + (size_t)nt * nch * 2;
+    }
+};
+
+// detector + selection of nt tiles, enqueue only: kp_out (nt x limit x 3) and counts (nt) on the device
+int fast_select_enqueue(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int margin, int threshold, int limit, FastScratch& fs,
+                        int* kp_out, int* counts)
+{
+    const int Pi = P - 2 * margin;
+    MaProfScope ps(ctx, MA_K_OTHER, (double)nt * Pi * Pi);
+    const dim3 grid((Pi + 255) / 256, Pi, nt);
+    MA_HIP(hipMemsetAsync(fs.tile_hist, 0, (size_t)nt * 256 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, ctx->stream, tiles, P, margin, threshold, fs.raw);
+    hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, ctx->stream, (const int*)fs.raw, Pi, fs.nms);
+    // selection: chunk histograms -> cut-off and chunk bases -> keys -> sort (one block per tile only for the sort)
+    hipLaunchKernelGGL(kp_chunk_hist_kernel, dim3(fs.nch, nt), dim3(KC_T), 0, ctx->stream, (const int*)fs.nms, (int)fs.npx, fs.nch,
+                       fs.chunk_hist, fs.tile_hist);
+    hipLaunchKernelGGL(kp_cut_kernel, dim3(nt), dim3(KC_T), 0, ctx->stream, (const int*)fs.chunk_hist, (const int*)fs.tile_hist,
+                       fs.nch, limit, fs.cut, fs.chunk_base);
+    hipLaunchKernelGGL(kp_collect_kernel, dim3(fs.nch, nt), dim3(KC_T), 0, ctx->stream, (const int*)fs.nms, (int)fs.npx, fs.nch,
+                       (const int*)fs.cut, (const int*)fs.chunk_base, fs.keys);
+    hipLaunchKernelGGL(kp_sort_kernel, dim3(nt), dim3(KS_T), 0, ctx->stream, (const unsigned long long*)fs.keys, (const int*)fs.cut,
+                       Pi, limit, kp_out, counts);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
+// The small tables of the descriptor -- 8 (cos, sin) pairs, 25 (dy, dx) offsets, three centre-first half kernels (+ 64
+// doubles: the smoothing kernels read a whole bucket of weights) -- as an immutable device copy, cached per device and
+// content for the life of the process (a register() asks for the same tables a dozen times).
+struct DaisyTables { const double* dev; size_t woff[3]; };
+std::mutex g_dt_mu;
+std::map<std::pair<int, std::vector<double>>, const double*> g_dt;
+
+int daisy_tables(ma_ctx* ctx, const double* const* weights_host, const int* radii, const double* cos_sin_host,
+                 const double* offs_host, DaisyTables& out)
+{
+    const size_t ntab = 16 + 50 + (size_t)(radii[0] + radii[1] + radii[2] + 3);
+    std::vector<double> tab(ntab + 64, 0.0);
+    for (int i = 0; i < 16; i++) tab[i] = cos_sin_host[i];
+    for (int i = 0; i < 50; i++) tab[16 + i] = offs_host[i];
+    size_t o = 66;
+    for (int c = 0; c < 3; c++) {
+        out.woff[c] = o;
+        for (int j = 0; j <= radii[c]; j++) tab[o++] = weights_host[c][j];
+    }
+    std::lock_guard<std::mutex> lk(g_dt_mu);
+    auto key = std::make_pair(ctx->device, tab);
+    auto it = g_dt.find(key);
+    if (it == g_dt.end()) {
+        double* d = nullptr;
+        MA_HIP(hipMalloc((void**)&d, tab.size() * sizeof(double)));
+        MA_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+        it = g_dt.emplace(std::move(key), d).first;
+    }
+    out.dev = it->second;
+    return MA_OK;
+}
+
+// layers -> three cubes -> descriptors for the keypoints (kp_tile, kp_xy) of nt tiles, enqueue only.  cubes: 4 x (nt x 8
+// planes of P x P float32); rects (device): content rectangle per tile; span: the largest content extent (host).
+// nkp: keypoints (an upper bound when nkp_dev holds the count on the device).
+int daisy_enqueue(ma_ctx* ctx, const void* tiles, int dtype, int nt, int P, const DaisyTables& tb, const int* radii,
+                  float* cubes, const DzRect* rects, DzSpan span, const int* kp_tile, const double* kp_xy, int nkp,
+                  const int* nkp_dev, float* desc_out)
+{
+    const size_t cube = (size_t)nt * 8 * P * P;
+    float* tmp = cubes + 3 * cube;
+    MaProfScope ps(ctx, MA_K_OTHER, (double)nt * P * P);
+    {
+        const dim3 grid((std::min(P, span.w + 2) + 255) / 256, std::min(P, span.h + 2), nt);
+        if (dtype == MA_U8) hipLaunchKernelGGL((daisy_layers_kernel<uint8_t>), grid, dim3(256), 0, ctx->stream, (const uint8_t*)tiles, P, tb.dev, tmp, (const int4*)rects);
+        else hipLaunchKernelGGL((daisy_layers_kernel<float>), grid, dim3(256), 0, ctx->stream, (const float*)tiles, P, tb.dev, tmp, (const int4*)rects);
+    }
+    const float* src = tmp;   // the orientation layers; smoothed successively: cube c = G(inc_c) * cube c-1
+    int h = 1, halo[3];
+    for (int c = 0; c < 3; c++) {
+        float* dst = cubes + c * cube;
+        // scipy filters axis 1 (y) first, then axis 2 (x), each pass rounding to float32.  The intermediate of the two
+        // passes lives in the next cube's slot (not yet written) or, for the last cube, in the layer buffer (done with)
+        float* mid = c < 2 ? cubes + (c + 1) * cube : tmp;
+        smooth_planes(ctx->stream, src, mid, dst, P, nt * 8, tb.dev + tb.woff[c], radii[c], rects, h, span);
+        h += radii[c];
+        halo[c] = h;
+        src = dst;
+    }
+    hipLaunchKernelGGL(daisy_sample_kernel, dim3(((size_t)nkp * 25 + 255) / 256), dim3(256), 0, ctx->stream, (const float*)cubes, cube,
+                       P, kp_tile, kp_xy, tb.dev + 16, nkp, nkp_dev, desc_out, rects, halo[0], halo[1], halo[2]);
+    MA_HIP(hipGetLastError());
+    return MA_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -433,39 +690,15 @@ int ma_fast_keypoints(ma_ctx* ctx, const uint8_t* tiles, int nt, int P, int marg
     MA_REQUIRE(threshold >= 0 && threshold < 254, "bad threshold");
     MA_HIP(hipSetDevice(ctx->device));
     const int Pi = P - 2 * margin;
-    const size_t npx = (size_t)Pi * Pi, map = (size_t)nt * npx * sizeof(int);
-    const int nch = (int)((npx + KC_CH - 1) / KC_CH);
+    int nch = 0;
+    const size_t need = FastScratch::size(nt, Pi, nch);
     MA_REQUIRE(nch <= 65535 * 32, "tile too large");
-    // workspace: raw scores, suppressed scores, per-chunk histograms, key lists, tile histograms, chunk bases, cuts, counts
-    const size_t b_ch = (size_t)nt * nch * 256 * sizeof(int), b_keys = (size_t)nt * KS_CAP * sizeof(unsigned long long),
-                 b_th = (size_t)nt * 256 * sizeof(int), b_cb = (size_t)nt * nch * 2 * sizeof(int), b_cut = (size_t)nt * 4 * sizeof(int);
-    MA_TRY(ma_ws_reserve(ctx, 2 * map + b_keys + b_ch + b_th + b_cb + b_cut + (size_t)nt * sizeof(int) + 64));
+    MA_TRY(ma_ws_reserve(ctx, need + (size_t)nt * sizeof(int) + 64));
     MA_TRY(ma_pinned_reserve(ctx, (size_t)nt * sizeof(int)));
-    int* raw = (int*)ctx->ws;
-    int* nms = raw + (size_t)nt * npx;
-    unsigned long long* keys = (unsigned long long*)((char*)ctx->ws + ma_align_up(2 * map, 8));
-    int* chunk_hist = (int*)(keys + (size_t)nt * KS_CAP);
-    int* tile_hist = chunk_hist + (size_t)nt * nch * 256;
-    int* chunk_base = tile_hist + (size_t)nt * 256;
-    int* cut = chunk_base + (size_t)nt * nch * 2;
-    int* counts = cut + (size_t)nt * 4;
-    {
-        MaProfScope ps(ctx, MA_K_OTHER, (double)nt * Pi * Pi);
-        const dim3 grid((Pi + 255) / 256, Pi, nt);
-        MA_HIP(hipMemsetAsync(tile_hist, 0, b_th, ctx->stream));
-        hipLaunchKernelGGL(fast_score_kernel, grid, dim3(256), 0, ctx->stream, tiles, P, margin, threshold, raw);
-        hipLaunchKernelGGL(fast_nms_kernel, grid, dim3(256), 0, ctx->stream, (const int*)raw, Pi, nms);
-        // selection: chunk histograms -> cut-off and chunk bases -> keys -> sort (one block per tile only for the sort)
-        hipLaunchKernelGGL(kp_chunk_hist_kernel, dim3(nch, nt), dim3(KC_T), 0, ctx->stream, (const int*)nms, (int)npx, nch,
-                           chunk_hist, tile_hist);
-        hipLaunchKernelGGL(kp_cut_kernel, dim3(nt), dim3(KC_T), 0, ctx->stream, (const int*)chunk_hist, (const int*)tile_hist, nch,
-                           limit, cut, chunk_base);
-        hipLaunchKernelGGL(kp_collect_kernel, dim3(nch, nt), dim3(KC_T), 0, ctx->stream, (const int*)nms, (int)npx, nch,
-                           (const int*)cut, (const int*)chunk_base, keys);
-        hipLaunchKernelGGL(kp_sort_kernel, dim3(nt), dim3(KS_T), 0, ctx->stream, (const unsigned long long*)keys, (const int*)cut,
-                           Pi, limit, kp_out, counts);
-        MA_HIP(hipGetLastError());
-    }
+    FastScratch fs;
+    fs.place(ctx->ws, nt, Pi);
+    int* counts = (int*)((char*)ctx->ws + ma_align_up(need, 64));
+    MA_TRY(fast_select_enqueue(ctx, tiles, nt, P, margin, threshold, limit, fs, kp_out, counts));
     MA_HIP(hipMemcpyAsync(ctx->pinned, counts, (size_t)nt * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));
     for (int t = 0; t < nt; t++) counts_host[t] = ((const int*)ctx->pinned)[t];
@@ -496,44 +729,102 @@ int ma_daisy_describe(ma_ctx* ctx, const void* tiles, int dtype, int nt, int P, 
     MA_REQUIRE(nt >= 1 && nt * 8 <= 65535 && P >= 1 && P <= 65535 && nkp >= 1, "bad tile geometry");
     MA_REQUIRE(radii[0] >= 0 && radii[1] >= 0 && radii[2] >= 0 && radii[0] + radii[1] + radii[2] < 4096, "bad radii");
     MA_HIP(hipSetDevice(ctx->device));
-    // small tables: 8 (cos, sin) pairs, 25 (dy, dx) offsets, three centre-first half kernels
-    const size_t ntab = 16 + 50 + (size_t)(radii[0] + radii[1] + radii[2] + 3);
-    MA_TRY(ma_dconst_reserve(ctx, (ntab + 64) * sizeof(double)));   // + 64: the smoothing kernels read a whole bucket of weights
-    std::vector<double> tab(ntab);
-    for (int i = 0; i < 16; i++) tab[i] = cos_sin_host[i];
-    for (int i = 0; i < 50; i++) tab[16 + i] = offs_host[i];
-    size_t woff[3], o = 66;
-    for (int c = 0; c < 3; c++) {
-        woff[c] = o;
-        for (int j = 0; j <= radii[c]; j++) tab[o++] = weights_host[c][j];
-    }
-    double* dtab = (double*)ctx->dconst;
-    MA_HIP(hipMemcpyAsync(dtab, tab.data(), ntab * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    MA_HIP(hipStreamSynchronize(ctx->stream));   // `tab` goes out of scope
-
-    // workspace: cubes 0..2 and one temporary, each nt x 8 planes of P x P float32
+    DaisyTables tb;
+    MA_TRY(daisy_tables(ctx, weights_host, radii, cos_sin_host, offs_host, tb));
+    // workspace: cubes 0..2 and one temporary, each nt x 8 planes of P x P float32, then the content rectangles: arbitrary
+    // tiles -- the whole tile counts as content
     const size_t cube = (size_t)nt * 8 * P * P;
-    MA_TRY(ma_ws_reserve(ctx, 4 * cube * sizeof(float)));
-    float* cubes = (float*)ctx->ws;
-    float* tmp = cubes + 3 * cube;
-    MaProfScope ps(ctx, MA_K_OTHER, (double)nt * P * P);
-    {
-        const dim3 grid((P + 255) / 256, P, nt);
-        if (dtype == MA_U8) hipLaunchKernelGGL((daisy_layers_kernel<uint8_t>), grid, dim3(256), 0, ctx->stream, (const uint8_t*)tiles, P, dtab, tmp);
-        else hipLaunchKernelGGL((daisy_layers_kernel<float>), grid, dim3(256), 0, ctx->stream, (const float*)tiles, P, dtab, tmp);
+    MA_TRY(ma_ws_reserve(ctx, 4 * cube * sizeof(float) + (size_t)nt * sizeof(DzRect)));
+    MA_TRY(ma_pinned_reserve(ctx, (size_t)nt * sizeof(DzRect)));
+    DzRect* h_rects = (DzRect*)ctx->pinned;
+    for (int t = 0; t < nt; t++) h_rects[t] = DzRect{0, P, 0, P};
+    DzRect* rects = (DzRect*)((float*)ctx->ws + 4 * cube);
+    MA_HIP(hipMemcpyAsync(rects, h_rects, (size_t)nt * sizeof(DzRect), hipMemcpyHostToDevice, ctx->stream));
+    return daisy_enqueue(ctx, tiles, dtype, nt, P, tb, radii, (float*)ctx->ws, rects, DzSpan{P, P}, kp_tile, kp_xy, nkp, nullptr,
+                         desc_out);
+}
+
+int ma_feature_extract(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int threshold, int limit,
+                       const double* const* weights_host, const int* radii, const double* cos_sin_host, const double* offs_host,
+                       size_t workspace_bytes, int capacity, float* desc_out, double* pts_out, int* resp_out, int* n_out_host)
+{
+    MA_REQUIRE(ctx && img && weights_host && radii && cos_sin_host && offs_host && desc_out && pts_out && resp_out && n_out_host,
+               "NULL argument");
+    MA_REQUIRE(H > 0 && W > 0 && tile > 0 && overlap >= 0 && tile <= 46340 && tile + 2 * overlap <= 65535, "bad tile geometry");
+    MA_REQUIRE(limit >= 1 && limit <= KS_CAP, "limit must be in [1, 8192]");
+    MA_REQUIRE(threshold >= 0 && threshold < 254, "bad threshold");
+    MA_REQUIRE(radii[0] >= 0 && radii[1] >= 0 && radii[2] >= 0 && radii[0] + radii[1] + radii[2] < 4096, "bad radii");
+    const int ntx = (W + tile - 1) / tile, nty = (H + tile - 1) / tile, P = tile + 2 * overlap, Pi = tile;
+    const long long n_tiles = (long long)ntx * nty;
+    MA_REQUIRE(n_tiles * limit <= capacity, "capacity must hold limit keypoints per tile");
+    MA_HIP(hipSetDevice(ctx->device));
+    *n_out_host = 0;
+    DaisyTables tb;
+    MA_TRY(daisy_tables(ctx, weights_host, radii, cos_sin_host, offs_host, tb));
+    // tiles per batch: the DAISY cubes (128 P^2 bytes per tile) within the budget, 8 planes per tile within a grid dimension
+    int nch = 0;
+    const size_t cube_tile = (size_t)4 * 8 * P * P * sizeof(float);
+    const size_t budget = workspace_bytes ? workspace_bytes : (size_t)8 << 30;
+    const int step = (int)std::max<size_t>(1, std::min<size_t>({budget / cube_tile, (size_t)(65535 / 8), (size_t)n_tiles}));
+    const size_t fast_bytes = FastScratch::size(step, Pi, nch);
+    MA_REQUIRE(nch <= 65535 * 32, "tile too large");
+    // one buffer: [tiles][kp_out][kp_tile][kp_xy][counts, base][rects][info][ detector scratch | cubes ]
+    const size_t b_tiles = ma_align_up((size_t)step * P * P, 256), b_kp = ma_align_up((size_t)step * limit * 3 * sizeof(int), 256),
+                 b_kt = ma_align_up((size_t)step * limit * sizeof(int), 256), b_xy = ma_align_up((size_t)step * limit * 16, 256),
+                 b_cnt = ma_align_up((size_t)step * 2 * sizeof(int), 256), b_rect = ma_align_up((size_t)step * sizeof(DzRect), 256);
+    const int n_batches = (int)((n_tiles + step - 1) / step);
+    const size_t b_info = ma_align_up((size_t)(2 * n_batches + 1) * sizeof(int), 256);
+    const size_t fixed = b_tiles + b_kp + b_kt + b_xy + b_cnt + b_rect + b_info;
+    MA_TRY(ma_ws_reserve(ctx, fixed + std::max(fast_bytes, (size_t)step * cube_tile)));
+    MA_TRY(ma_pinned_reserve(ctx, (size_t)step * sizeof(DzRect) * (size_t)n_batches + 64));
+    char* ws = (char*)ctx->ws;
+    uint8_t* tiles = (uint8_t*)ws;
+    int* kp = (int*)(ws + b_tiles);
+    int* kp_tile = (int*)(ws + b_tiles + b_kp);
+    double* kp_xy = (double*)(ws + b_tiles + b_kp + b_kt);
+    int* counts = (int*)(ws + b_tiles + b_kp + b_kt + b_xy);
+    int* base = counts + step;
+    DzRect* rects = (DzRect*)(ws + b_tiles + b_kp + b_kt + b_xy + b_cnt);
+    int* info = (int*)(ws + b_tiles + b_kp + b_kt + b_xy + b_cnt + b_rect);
+    int* total = info + 2 * n_batches;
+    char* big = ws + fixed;
+    MA_HIP(hipMemsetAsync(total, 0, sizeof(int), ctx->stream));
+    DzRect* h_rects_all = (DzRect*)((char*)ctx->pinned + 64);
+    for (int bi = 0; bi < n_batches; bi++) {
+        const int first = bi * step, nb = (int)std::min<long long>(step, n_tiles - first);
+        // content of window t: image rows [ty T - ov, ty T - ov + P) cut to the image, in window coordinates
+        DzRect* h_rects = h_rects_all + (size_t)bi * step;
+        DzSpan span{0, 0};
+        for (int k = 0; k < nb; k++) {
+            const int t = first + k, ty = t / ntx, tx = t - ty * ntx, wy = ty * tile - overlap, wx = tx * tile - overlap;
+            DzRect r{std::max(0, -wy), std::min(P, H - wy), std::max(0, -wx), std::min(P, W - wx)};
+            if (r.y1 <= r.y0 || r.x1 <= r.x0) r = DzRect{0, 0, 0, 0};
+            h_rects[k] = r;
+            span.h = std::max(span.h, r.y1 - r.y0);
+            span.w = std::max(span.w, r.x1 - r.x0);
+        }
+        MA_HIP(hipMemcpyAsync(rects, h_rects, (size_t)nb * sizeof(DzRect), hipMemcpyHostToDevice, ctx->stream));
+        {
+            MaProfScope ps(ctx, MA_K_OTHER, (double)nb * P * P);
+            hipLaunchKernelGGL(cut_tiles_kernel, dim3((P + 255) / 256, P, nb), dim3(256), 0, ctx->stream, img, H, W, tile, overlap, ntx,
+                               P, first, tiles);
+        }
+        FastScratch fs;
+        fs.place(big, nb, Pi);
+        MA_TRY(fast_select_enqueue(ctx, tiles, nb, P, overlap, threshold, limit, fs, kp, counts));
+        hipLaunchKernelGGL(kp_offsets_kernel, dim3(1), dim3(64), 0, ctx->stream, (const int*)counts, nb, base, info + 2 * bi, total);
+        hipLaunchKernelGGL(kp_compact_kernel, dim3((limit + 255) / 256, nb), dim3(256), 0, ctx->stream, (const int*)kp,
+                           (const int*)counts, (const int*)base, (const int*)(info + 2 * bi), limit, tile, ntx, first, kp_tile,
+                           kp_xy, pts_out, resp_out);
+        MA_HIP(hipGetLastError());
+        // the descriptors of the batch land behind those of the batches before it: the sample kernel takes the count and the
+        // offset from the device (info[0], info[1])
+        MA_TRY(daisy_enqueue(ctx, tiles, MA_U8, nb, P, tb, radii, (float*)big, rects, span, kp_tile, kp_xy, nb * limit,
+                             info + 2 * bi, desc_out));
     }
-    const float* src = tmp;   // the orientation layers; smoothed successively: cube c = G(inc_c) * cube c-1
-    for (int c = 0; c < 3; c++) {
-        float* dst = cubes + c * cube;
-        // scipy filters axis 1 (y) first, then axis 2 (x), each pass rounding to float32.  The intermediate of the two
-        // passes lives in the next cube's slot (not yet written) or, for the last cube, in the layer buffer (done with)
-        float* mid = c < 2 ? cubes + (c + 1) * cube : tmp;
-        smooth_planes(ctx->stream, src, mid, dst, P, nt * 8, dtab + woff[c], radii[c]);
-        src = dst;
-    }
-    hipLaunchKernelGGL(daisy_sample_kernel, dim3((nkp * 25 + 255) / 256), dim3(256), 0, ctx->stream, (const float*)cubes, cube, P,
-                       kp_tile, kp_xy, dtab + 16, nkp, desc_out);
-    MA_HIP(hipGetLastError());
+    MA_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MA_HIP(hipStreamSynchronize(ctx->stream));
+    *n_out_host = *(const int*)ctx->pinned;
     return MA_OK;
 }
 

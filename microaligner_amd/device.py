@@ -894,6 +894,36 @@ class Context:
                   n, desc.ptr)
         return desc if on_device else desc.numpy()
 
+    def feature_extract(self, img, tile, overlap, limit, weights, cos_sin, offsets, threshold=1, workspace_bytes=0):
+        """tile_registration.find_features of a uint8 device image in one call (ma_feature_extract): returns
+        (descriptors (n, 200) float32 DeviceArray, points (n, 2) float64 raw device buffer, responses (n,) int32 raw device
+        buffer, n); everything stays on the device, the keypoint count is the only thing that comes back."""
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise ValueError("FAST works on uint8 images (the DOG output)")
+        H, W = img.shape
+        n_tiles = -(-H // tile) * -(-W // tile)
+        cap = n_tiles * int(limit)
+        desc = self.empty((cap, 200), np.float32)
+        pts, resp = self._raw(cap * 16), self._raw(cap * 4)
+        halves = [np.ascontiguousarray(w, np.float64) for w in weights]
+        wptr = (C.POINTER(C.c_double) * 3)(*[h.ctypes.data_as(C.POINTER(C.c_double)) for h in halves])
+        radii = (C.c_int * 3)(*[len(h) - 1 for h in halves])
+        cs = np.ascontiguousarray(cos_sin, np.float64)
+        of = np.ascontiguousarray(offsets, np.float64)
+        n = C.c_int(0)
+        self._run(self.lib.ma_feature_extract, img.ptr, H, W, int(tile), int(overlap), int(threshold), int(limit), wptr, radii,
+                  cs.ctypes.data_as(C.POINTER(C.c_double)), of.ctypes.data_as(C.POINTER(C.c_double)), int(workspace_bytes), cap,
+                  desc.ptr, pts.ptr, resp.ptr, C.byref(n))
+        desc.shape = (n.value, 200)
+        return desc, pts, resp, n.value
+
+    def download_raw(self, buf, shape, dtype):
+        """A raw device buffer (_raw) as a host array of the given shape and dtype."""
+        out = np.empty(shape, dtype)
+        if out.nbytes:
+            L.check(self.lib.ma_memcpy_d2h(self.handle, out.ctypes.data, buf.ptr, out.nbytes))
+        return out
+
     def to_f32(self, arr):
         """Mat::convertTo(CV_32F): exact for the integer dtypes (ma_convert_f32); float32 arrays pass through."""
         if arr.dtype == np.float32:

@@ -21,13 +21,45 @@ class Features:
     """Keypoints + descriptors of one image (or tile).  `keypoints` is a list of KeyPoint (pt, size, angle,
     response, octave, class_id -- the cv2.KeyPoint fields the reference serialises) or None.  The device path keeps
     the points as arrays (`pts` (n, 2) float64 (x, y), `responses` (n,)) and builds the KeyPoint list only when somebody
-    asks for it: a level of a 4096^2 image has ~45 000 of them per image and iteration."""
+    asks for it: a level of a 4096^2 image has ~45 000 of them per image and iteration.  Features that
+    ma_feature_extract made live on the device altogether (descriptors, points, responses): `pts`, `responses` and
+    `descriptors` download them when asked for, the matching step (ma_knn2_l2, ma_match_similarity) never does."""
 
     def __init__(self):
         self._keypoints: Optional[List[KeyPoint]] = None
-        self.pts: Optional[np.ndarray] = None
-        self.responses: Optional[np.ndarray] = None
+        self._pts: Optional[np.ndarray] = None
+        self._responses: Optional[np.ndarray] = None
         self._descriptors = None           # ndarray (n, 200) float32, or a DeviceArray that is downloaded when asked for
+        self._dev = None                   # (ctx, points buffer, responses buffer, n) of device-made features
+        self._pts_dev = None
+
+    @classmethod
+    def on_device(cls, ctx, desc, pts, resp, n):
+        f = cls()
+        f._descriptors, f._dev, f._pts_dev = desc, (ctx, pts, resp, n), pts
+        return f
+
+    @property
+    def pts(self) -> Optional[np.ndarray]:
+        if self._pts is None and self._dev is not None:
+            ctx, pts, _, n = self._dev
+            self._pts = ctx.download_raw(pts, (n, 2), np.float64)
+        return self._pts
+
+    @pts.setter
+    def pts(self, v):
+        self._pts, self._pts_dev = v, None
+
+    @property
+    def responses(self) -> Optional[np.ndarray]:
+        if self._responses is None and self._dev is not None:
+            ctx, _, resp, n = self._dev
+            self._responses = ctx.download_raw(resp, (n,), np.int32).astype(np.float64)
+        return self._responses
+
+    @responses.setter
+    def responses(self, v):
+        self._responses = v
 
     @property
     def descriptors(self) -> Optional[np.ndarray]:
@@ -61,11 +93,11 @@ class Features:
             self.pts = self.responses = None
 
     def is_valid(self) -> bool:
-        return self.pts is not None and self._descriptors is not None
+        return (self._pts is not None or self._dev is not None) and self._descriptors is not None
 
     def device_pts(self, ctx):
         """The keypoint positions as an (n, 2) float64 device buffer (uploaded once per Features object)."""
-        if getattr(self, "_pts_dev", None) is None:
+        if self._pts_dev is None:
             self._pts_dev = ctx._upload_raw(np.ascontiguousarray(self.pts, np.float64))
         return self._pts_dev
 
@@ -221,42 +253,27 @@ def find_features_device(tile_list: Sequence[np.ndarray], ctx, workspace_bytes: 
 
 
 def find_features_of_device_image(img, tile_size: int, ctx, workspace_bytes: Optional[int] = None):
-    """tile_registration.find_features for a uint8 image that is already on the device (the DOG output): the feature
-    windows are cut there (ma_cut_tiles_u8), the corners detected, ranked and cut to the per-tile limit there
-    (ma_fast_keypoints), the descriptors computed and LEFT there (ma_daisy_describe) for the 2-NN search.  Only the
-    selected keypoints -- a few thousand (x, y, response) triples per tile -- come back to the host.  Returns the
-    combined Features in image coordinates (combine_features' layout: tile by tile, strongest first within a tile)."""
+    """tile_registration.find_features for a uint8 image that is already on the device (the DOG output), in one call
+    (ma_feature_extract): the feature windows are cut there, the corners detected, ranked and cut to the per-tile limit
+    there, the selection compacted in combine_features' layout (tile by tile, strongest first within a tile, tiles with
+    fewer than three keypoints dropped, image coordinates) and the descriptors computed there -- and everything is LEFT
+    there for the matching step; the number of keypoints is all that comes back.  Returns the combined Features; their
+    `pts` / `responses` / `descriptors` download on demand."""
     from ..shared_modules.tiling import TileGrid
     H, W = img.shape
     grid = TileGrid(H, W, tile_size, TILE_OVERLAP)
     n_tiles, P = grid.ntiles, grid.window
-    combined = Features()
-    if P <= 2 * TILE_OVERLAP:
-        return combined
     limit = min(1000000 // n_tiles, 5000)
+    if P <= 2 * TILE_OVERLAP or limit < 1:
+        return Features()
     daisy = Daisy(radius=21, q_radius=3, q_theta=8, q_hist=8)
     halves, cos_sin, offsets = _daisy_tables(daisy)
     budget = DEVICE_WORKSPACE_BYTES if workspace_bytes is None else int(workspace_bytes)
-    pts, responses, descs = [], [], []
-    for batch in _device_batches(n_tiles, P, budget):
-        d_tiles = ctx.cut_tiles(img, tile_size, TILE_OVERLAP, batch[0], len(batch))
-        counts, kp = ctx.fast_keypoints(d_tiles, TILE_OVERLAP, limit, threshold=1)
-        keep = [k for k in range(len(batch)) if counts[k] >= 3]      # feature_detection.py:112-115
-        if not keep:
-            continue
-        kp_tile = np.concatenate([np.full(counts[k], k, np.int32) for k in keep])
-        kp_xy = np.concatenate([kp[k, :counts[k], :2] for k in keep]).astype(np.float64)
-        descs.append(ctx.daisy_describe(d_tiles, kp_tile, kp_xy, halves, cos_sin, offsets, on_device=True))
-        for k in keep:
-            t = batch[k]
-            origin = np.array([t % grid.nx * tile_size, t // grid.nx * tile_size], np.float64)
-            pts.append(kp[k, :counts[k], :2].astype(np.float64) + origin)
-            responses.append(kp[k, :counts[k], 2].astype(np.float64))
-    if pts:
-        combined.pts = np.concatenate(pts, axis=0)
-        combined.responses = np.concatenate(responses)
-        combined.descriptors = descs[0] if len(descs) == 1 else np.concatenate([d.numpy() for d in descs], axis=0)
-    return combined
+    desc, pts, resp, n = ctx.feature_extract(img, tile_size, TILE_OVERLAP, limit, halves, cos_sin, offsets, threshold=1,
+                                             workspace_bytes=budget)
+    if n == 0:
+        return Features()
+    return Features.on_device(ctx, desc, pts, resp, n)
 
 
 def find_features_parallelized(tile_list: Sequence[np.ndarray], workers: Optional[int] = None) -> List[Features]:

@@ -45,8 +45,10 @@ class FeatureRegistrator:
         self.verbose = True      # addition: the reference prints unconditionally
         self.compat_mov_getter = True   # the mov_img getter returns the REFERENCE image, as the reference's does; False: the moving image
         self._levels: List[_Level] = []   # reference side, coarsest first; kept for register(reuse_ref_img=True)
-        self._careful = False             # True: dog() synchronises for its max() == 0 report (see register())
-        self._log_buf = None              # list of held-back log lines during the fast attempt of register()
+        self._careful = False             # True: register() runs in the careful mode only (see register())
+        self._fast = False                # True while register()'s fast attempt runs: dog() defers its max() == 0 report
+        self._log_buf = None              # log lines of the fast attempt that no synchronisation point has confirmed yet
+        self._log_shown = 0               # lines of the fast attempt already printed (a restart does not repeat them)
 
     # -- inputs ---------------------------------------------------------------------------------------------
     @property
@@ -70,11 +72,15 @@ class FeatureRegistrator:
         self._mov_img = img
 
     def _log(self, *args):
-        # in the fast attempt of register() the lines are kept back until the attempt stands (per object: no process-wide
-        # redirection of stdout, which threads registering side by side would trip over)
+        # In the fast attempt of register() a line is held back until the next synchronisation point has confirmed that no
+        # dog() before it met an all-zero image (_check_deferred prints what it confirms: progress shows as it happens); the
+        # careful re-run after a restart reproduces the confirmed lines and skips them.  Per object: no process-wide
+        # redirection of stdout, which threads registering side by side would trip over.
         if self.verbose:
             if self._log_buf is not None:
                 self._log_buf.append(" ".join(str(a) for a in args))
+            elif self._log_shown > 0:
+                self._log_shown -= 1
             else:
                 print(*args)
 
@@ -100,21 +106,25 @@ class FeatureRegistrator:
         # Fast path: dog() does not wait for the device to learn whether its input's max() is 0 (the reference's shortcut,
         # :288-291); the flags are collected at the synchronisation points the rounds have anyway.  If one turns out set --
         # an all-black level, a transform that moved everything out of view -- the call starts over in the careful mode,
-        # which asks after every dog() as the reference does.
+        # which asks after every dog() as the reference does.  The deferred reports exist only between here and the end of
+        # the attempt: the public dog() and calc_ref_img_features() outside register() are synchronous.
         if self._careful:
             return self._register(reuse_ref_img)
-        self._log_buf = []      # the attempt's lines (this class's and the matchers') are shown once it stands
+        get_context().any_deferred_zero()       # flags an aborted attempt (of any registrator on this context) left behind
+        self._log_buf, self._log_shown, self._fast = [], 0, True
         try:
             result = self._register(reuse_ref_img)
         except _ZeroMaxImage:
-            self._log_buf = None
+            self._log_buf, self._fast = None, False
             self._levels = []
             self._careful = True
             try:
-                return self._register(False)
+                return self._register(False)      # prints from the first line the fast attempt had not shown
             finally:
                 self._careful = False
+                self._log_shown = 0
         finally:
+            self._fast = False
             held, self._log_buf = self._log_buf, None
             for line in held or ():
                 print(line)
@@ -180,10 +190,12 @@ class FeatureRegistrator:
         return [(factor, by_steps[steps]) for factor, steps in plan]
 
     # -- one level ------------------------------------------------------------------------------------------
-    def _features_of(self, img) -> Features:
-        """Features of dog(img) (or of img itself with use_dog off): tiles cut on the host, dense work on the device."""
+    def _features_of(self, img, pre=None) -> Features:
+        """Features of dog(img) (or of img itself with use_dog off); `pre`: that image when the caller has it already.
+        A uint8 device image goes through ma_feature_extract in one call, anything else is cut into tiles on the host."""
         ctx = get_context()
-        pre = self.dog(img, self.use_dog)
+        if pre is None:
+            pre = self.dog(img, self.use_dog)
         if isinstance(pre, DeviceArray) and pre.dtype == np.uint8:
             return find_features_of_device_image(pre, self.tile_size, ctx)
         host = pre.numpy() if isinstance(pre, DeviceArray) else np.asarray(pre)
@@ -193,21 +205,28 @@ class FeatureRegistrator:
         """:162-207: `num_iterations` rounds on one level.  A round estimates the similarity that maps the current
         image onto the reference features; it is kept only if the mutual-information gate prefers the transformed
         image and the matrix is plausible (affine_math), otherwise the round contributes the identity.  After a kept
-        round the ORIGINAL level is transformed by the product of the kept matrices (no resampling chain)."""
+        round the ORIGINAL level is transformed by the product of the kept matrices (no resampling chain).
+        dog(current) serves both the features (use_dog) and the gate; a kept FIRST round's candidate is the next current
+        image (the original level transformed by that one matrix: the same call on the same inputs)."""
         if self.num_iterations < 1:
             raise ValueError("Number of iterations cannot be less than 1")
         ctx = get_context()
         ref_gate = self.dog(ref_level.image, True)
         rounds: List[np.ndarray] = []
         current = mov_level
+        current_gate = None
         for it in range(self.num_iterations):
             self._log("    Iteration", it + 1, "/", self.num_iterations)
+            if current_gate is None:
+                current_gate = self.dog(current, True)
             # the exact 2-NN search over up to 45 000 x 45 000 descriptors, the ratio test and the RANSAC fit run on the device
             # (ma_knn2_l2, ma_match_similarity): the matrix and the match count come back
-            estimate = register_img_pair(ref_level.features, self._features_of(current), self.verbose, log=self._log, ctx=ctx)
+            mov_features = self._features_of(current, pre=current_gate if self.use_dog else None)
+            estimate = register_img_pair(ref_level.features, mov_features, self.verbose, log=self._log, ctx=ctx)
             is_identity = bool(np.array_equal(estimate, affine_math.IDENTITY))
             candidate = current if is_identity else self.transform_img(current, estimate)
-            improved = check_if_higher_similarity(ref_gate, self.dog(candidate, True), self.dog(current, True),
+            candidate_gate = current_gate if is_identity else self.dog(candidate, True)
+            improved = check_if_higher_similarity(ref_gate, candidate_gate, current_gate,
                                                   self.tile_size, self.verbose, log=self._log)
             plausible = (affine_math.centre_stays_inside(estimate, mov_level.shape)
                          and affine_math.scales_plausible(estimate))
@@ -215,7 +234,10 @@ class FeatureRegistrator:
             if any(improved) and plausible:
                 self._log("    Better alignment than before")
                 rounds.append(estimate)
-                current = self.transform_img(mov_level, affine_math.compose(rounds))
+                if len(rounds) == 1 and current is mov_level:
+                    current, current_gate = candidate, candidate_gate
+                else:
+                    current, current_gate = self.transform_img(mov_level, affine_math.compose(rounds)), None
             else:
                 self._log("    Worse alignment than before")
                 rounds.append(affine_math.IDENTITY.copy())
@@ -232,7 +254,7 @@ class FeatureRegistrator:
         if not use_it:
             return img
         ctx = get_context()
-        if not self._careful and isinstance(img, DeviceArray):
+        if self._fast and isinstance(img, DeviceArray):
             return ctx.dog_u8(img, low_sigma, high_sigma, report_zero="deferred")
         out, src_max_is_zero = ctx.dog_u8(ctx.asdevice(img), low_sigma, high_sigma, report_zero=True)
         if src_max_is_zero:
@@ -240,5 +262,13 @@ class FeatureRegistrator:
         return out if isinstance(img, DeviceArray) else out.numpy()
 
     def _check_deferred(self):
-        if not self._careful and get_context().any_deferred_zero():
+        """At a synchronisation point of the fast attempt: restart if a dog() since the last one met an all-zero image,
+        otherwise the lines held back so far stand and are printed."""
+        if not self._fast:
+            return
+        if get_context().any_deferred_zero():
             raise _ZeroMaxImage()
+        for line in self._log_buf or ():
+            print(line)
+        self._log_shown += len(self._log_buf or ())
+        self._log_buf = []

@@ -235,6 +235,11 @@ def test_keypoints_selected_on_the_device_equal_the_oracle_selection(ctx, shape,
     # the host-tile route gives the very same combined features
     old = TR.find_features(img, tile, ctx)
     assert np.array_equal(old.pts, got.pts) and np.array_equal(old.descriptors, got.descriptors)
+    # ... and so does ma_feature_extract when its workspace holds two tiles at a time (several batches, running offsets)
+    P = tile + 2 * FD.TILE_OVERLAP
+    batched = FD.find_features_of_device_image(d_img, tile, ctx, workspace_bytes=2 * 128 * P * P)
+    assert np.array_equal(batched.pts, got.pts) and np.array_equal(batched.responses, got.responses)
+    assert np.array_equal(batched.descriptors, got.descriptors)
     # the 2-NN search takes the descriptors where they are
     idx_d, dist_d = ctx.knn2(got.descriptors_for_search, got.descriptors_for_search)
     idx_h, dist_h = ctx.knn2(old.descriptors, old.descriptors)
