@@ -136,79 +136,118 @@ __device__ __forceinline__ DzRect dz_dilate(const DzRect c, int hy, int hx, int 
 }
 
 // The smoothing filter with the window of a thread in registers, sliding: the plane is read as [A][B] (B contiguous, one
-// thread per b), filtered along A for NY * NIT consecutive outputs per thread -- the window of NY + 2 RB inputs moves down by
-// NY rows per step, so every input row is loaded and converted ONCE per thread, and the rows of the next step are in flight
-// while this step's taps are applied -- and written TRANSPOSED, [B][A], through LDS.  Two launches make scipy's two passes:
-// y then x, the second one reading the transposed intermediate and transposing it back.  Per output the arithmetic is that
-// of smooth_axis_kernel, tap for tap: acc = x[0] w[0]; acc += (x[-j] + x[+j]) w[j], j = r .. 1.  Taps beyond r are skipped
-// by a uniform branch.
+// thread per b), filtered along A and written TRANSPOSED, [B][A], through LDS.  A block of SW waves covers 64 columns and
+// SW * NY * NIT consecutive outputs along A: its input rows -- the outputs' rows and RB more on either side, shared by the waves
+// -- are staged in LDS once, by all threads, with every load of the block in flight at the same time (the earlier form, in
+// which each thread loaded its own rows one by one, spent 70 % of its wave cycles waiting for them: profiles/r06_notes.md);
+// then every thread slides its window of NY + 2 RB inputs down its column of the LDS tile, NY rows per step.  Two launches
+// make scipy's two passes: y then x, the second one reading the transposed intermediate and transposing it back.  Per output
+// the arithmetic is that of smooth_axis_kernel, tap for tap: acc = x[0] w[0]; acc += (x[-j] + x[+j]) w[j], j = r .. 1.  Taps
+// beyond r are skipped by a uniform branch.
 // Geometry per plane (tile = plane / 8): the input holds values for a in [ia0, ia1), b in [b0, b1) -- the content rectangle
 // dilated by (h_a, h_b) -- and zeros elsewhere; outputs are made for a in [ia0 - r, ia1 + r) within the plane.  swap: 0 when
 // a runs along y (first pass), 1 when a runs along x (second pass, transposed input).
-constexpr int ST_B = 64;      // one wave per block: 64 columns b
+constexpr int ST_B = 64;      // columns b of a block: one per lane
 
-template <int RB, int NY, int NIT>
-__global__ __launch_bounds__(ST_B) void smooth_slide_kernel(const float* __restrict__ src, int A, int B,
-                                                            const double* __restrict__ w, int r, float* __restrict__ dst,
-                                                            const DzRect* __restrict__ rects, int h_a, int h_b, int swap)
+template <int RB, int NY, int NIT, int SW>
+__global__ __launch_bounds__(64 * SW) void smooth_slide_kernel(const float* __restrict__ src, int A, int B,
+                                                               const double* __restrict__ w, int r, float* __restrict__ dst,
+                                                               const DzRect* __restrict__ rects, int h_a, int h_b, int swap)
 {
-    constexpr int NA = NY * NIT, TP = NA + 1, WN = NY + 2 * RB;
-    __shared__ float tile[ST_B * TP];
-    const int lane = threadIdx.x;
+    constexpr int NA = NY * NIT, TP = NA + 1, WN = NY + 2 * RB, ROWS = SW * NA + 2 * RB;
+    static_assert(SW * ST_B * TP <= ROWS * ST_B, "the transposition tiles reuse the staging buffer");
+    extern __shared__ float stage[];                       // [ROWS][64] inputs; later SW x [64][TP] outputs
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     DzRect c = rects[blockIdx.z >> 3];
     if (swap) { DzRect t = c; c.y0 = t.x0; c.y1 = t.x1; c.x0 = t.y0; c.x1 = t.y1; }
     const DzRect vin = dz_dilate(c, h_a, h_b, A);          // A == B == P
     const int ia0 = vin.y0, ia1 = vin.y1, b0 = vin.x0 + blockIdx.x * ST_B, b1 = vin.x1;
     const int oa0 = max(ia0 - r, 0), oa1 = min(ia1 + r, A);
-    const int a00 = oa0 + blockIdx.y * NA;
-    if (b0 >= b1 || a00 >= oa1 || ia1 <= ia0) return;      // uniform: nothing of this plane in the block
-    const int b = min(b0 + lane, b1 - 1);                  // lanes past the edge compute a copy of the last column and store nothing
-    const float* s = src + (size_t)blockIdx.z * A * B + b;
-    auto row = [&](int a) -> float {                       // input row a of this thread's column: clamped like scipy's
-        const int ac = d_clamp(a, 0, A - 1);               // mode="nearest", zero outside the rows that hold values
-        const float v = s[(size_t)d_clamp(ac, ia0, ia1 - 1) * B];
-        return (ac >= ia0 && ac < ia1) ? v : 0.f;
-    };
-    double wv[RB + 1];
+    const int ablk = oa0 + blockIdx.y * (SW * NA);
+    if (b0 >= b1 || ablk >= oa1 || ia1 <= ia0) return;     // uniform: nothing of this plane in the block
+    {
+        // stage rows ablk - RB .. ablk + SW NA + RB: clamped like scipy's mode="nearest", zero outside the rows that hold
+        // values; lanes past the edge hold a copy of the last column (they compute and store nothing of their own)
+        const int b = min(b0 + lane, b1 - 1);
+        const float* s = src + (size_t)blockIdx.z * A * B + b;
+        const int last = min(ROWS, oa1 - ablk + 2 * RB);   // rows beyond the last output's window are not needed
+        // all loads of a thread first, then the LDS writes: as a plain loop the compiler waits for every load before it
+        // issues the next one (one memory latency per row; profiles/r06_notes.md)
+        constexpr int PER = (ROWS + SW - 1) / SW;
+        float tmp[PER];
 #pragma unroll
-    for (int j = 0; j <= RB; j++) wv[j] = w[j];            // the table is padded: entries beyond r exist and are not used
-    double win[WN];
-#pragma unroll
-    for (int i = 0; i < 2 * RB; i++) win[i] = (double)row(a00 - RB + i);
-    float nxt[NY];
-#pragma unroll
-    for (int i = 0; i < NY; i++) nxt[i] = row(a00 + RB + i);
-    for (int it = 0; it < NIT; it++) {
-        const int a0 = a00 + it * NY;
-        if (a0 >= oa1) break;
-#pragma unroll
-        for (int i = 0; i < NY; i++) win[2 * RB + i] = (double)nxt[i];
-        if (it + 1 < NIT) {                                // the next step's rows: in flight during this step's arithmetic
-#pragma unroll
-            for (int i = 0; i < NY; i++) nxt[i] = row(a0 + NY + RB + i);
-        }
-        double acc[NY];
-#pragma unroll
-        for (int o = 0; o < NY; o++) acc[o] = __dmul_rn(win[o + RB], wv[0]);
-#pragma unroll
-        for (int j = RB; j >= 1; j--) {
-            if (j <= r) {
-#pragma unroll
-                for (int o = 0; o < NY; o++)
-                    acc[o] = __dadd_rn(acc[o], __dmul_rn(__dadd_rn(win[o + RB - j], win[o + RB + j]), wv[j]));
-            }
+        for (int k = 0; k < PER; k++) {
+            const int i = wv + k * SW;
+            const int ac = d_clamp(ablk - RB + i, 0, A - 1);
+            float v = 0.f;
+            if (i < last && ac >= ia0 && ac < ia1) v = s[(size_t)ac * B];
+            tmp[k] = v;
         }
 #pragma unroll
-        for (int o = 0; o < NY; o++) tile[lane * TP + it * NY + o] = (float)acc[o];
-#pragma unroll
-        for (int i = 0; i < 2 * RB; i++) win[i] = win[i + NY];
+        for (int k = 0; k < PER; k++) {
+            const int i = wv + k * SW;
+            if (i < ROWS) stage[i * ST_B + lane] = tmp[k];
+        }
     }
     __syncthreads();
+    const int a00 = ablk + wv * NA;
+    const bool live = a00 < oa1;                           // wave-uniform: waves past the last output only keep the barriers
+    const float* col = stage + (wv * NA) * ST_B + lane;    // this thread's column, element i = input row a00 - RB + i
+    double wv_[RB + 1];
+#pragma unroll
+    for (int j = 0; j <= RB; j++) wv_[j] = w[j];           // the table is padded: entries beyond r exist and are not used
+    double win[WN];
+    float outv[NA];
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < 2 * RB; i++) win[i] = (double)col[i * ST_B];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            if (a00 + it * NY < oa1) {
+#pragma unroll
+                for (int i = 0; i < NY; i++) win[2 * RB + i] = (double)col[(2 * RB + it * NY + i) * ST_B];
+                double acc[NY];
+#pragma unroll
+                for (int o = 0; o < NY; o++) acc[o] = __dmul_rn(win[o + RB], wv_[0]);
+#pragma unroll
+                for (int j = RB; j >= 1; j--) {
+                    if (j <= r) {
+                        // the NY chains of a tap in three phases (sums, products, accumulation): left to itself the compiler
+                        // threads all of them through ONE temporary register pair and every instruction waits for the last
+                        double t[NY];
+#pragma unroll
+                        for (int o = 0; o < NY; o++) t[o] = __dadd_rn(win[o + RB - j], win[o + RB + j]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int o = 0; o < NY; o++) t[o] = __dmul_rn(t[o], wv_[j]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int o = 0; o < NY; o++) acc[o] = __dadd_rn(acc[o], t[o]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < NY; o++) outv[it * NY + o] = (float)acc[o];
+#pragma unroll
+                for (int i = 0; i < 2 * RB; i++) win[i] = win[i + NY];
+            }
+        }
+    }
+    __syncthreads();                                       // every window has been read: the buffer becomes the output tiles
+    float* tile = stage + wv * (ST_B * TP);
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) tile[lane * TP + i] = outv[i];
+    }
+    __syncthreads();
+    if (!live) return;
     float* d = dst + (size_t)blockIdx.z * A * B + a00;
     const int nb = min(ST_B, b1 - b0);
-    for (int a = lane; a < NA; a += 64) {
+    // rows of NA floats per column b; with NA < 64 a store instruction carries 64 / NA of them
+    constexpr int PER = NA >= 64 ? 1 : 64 / NA;
+    for (int a = lane % (64 / PER); a < NA; a += 64 / PER) {
         if (a00 + a < oa1) {
-            for (int bb = 0; bb < nb; bb++) d[(size_t)(b0 + bb) * A + a] = tile[bb * TP + a];
+            for (int bb = lane / (64 / PER); bb < nb; bb += PER) d[(size_t)(b0 + bb) * A + a] = tile[bb * TP + a];
         }
     }
 }
@@ -241,34 +280,56 @@ struct DzSpan { int h, w; };      // the largest content height / width over the
 
 // one smoothing pass pair (y, then x) of `planes` planes of P x P: src -> mid (transposed) -> dst.  h: halo the input has
 // accumulated; span: largest content extent.
-template <int RB, int NY, int NIT>
-static void smooth_pair(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r,
-                        const DzRect* rects, int h, DzSpan span)
+template <int RB, int NY, int NIT, int SW>
+static int smooth_pair_launch(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r,
+                              const DzRect* rects, int h, int in_h, int in_w, int out_h, int out_w)
 {
-    constexpr int NA = NY * NIT;
-    const int in_h = std::min(P, span.h + 2 * h), in_w = std::min(P, span.w + 2 * h);
-    const int out_h = std::min(P, in_h + 2 * r), out_w = std::min(P, in_w + 2 * r);
+    constexpr int NA = NY * NIT * SW;
+    constexpr size_t lds = (size_t)(NA + 2 * RB) * ST_B * sizeof(float);
+    static bool raised = false;         // per kernel instantiation; the attribute is per function, idempotent
+    if (!raised && lds > 64 * 1024) {
+        MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(smooth_slide_kernel<RB, NY, NIT, SW>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        raised = true;
+    }
     // pass 1: a = y (outputs out_h), b = x (in_w columns); pass 2: a = x (outputs out_w), b = y (out_h columns)
     const dim3 g1((in_w + ST_B - 1) / ST_B, (out_h + NA - 1) / NA, planes), g2((out_h + ST_B - 1) / ST_B, (out_w + NA - 1) / NA, planes);
-    hipLaunchKernelGGL((smooth_slide_kernel<RB, NY, NIT>), g1, dim3(ST_B), 0, stream, src, P, P, w, r, mid, rects, h, h, 0);
-    hipLaunchKernelGGL((smooth_slide_kernel<RB, NY, NIT>), g2, dim3(ST_B), 0, stream, (const float*)mid, P, P, w, r, dst, rects, h, h + r, 1);
+    hipLaunchKernelGGL((smooth_slide_kernel<RB, NY, NIT, SW>), g1, dim3(64 * SW), lds, stream, src, P, P, w, r, mid, rects, h, h, 0);
+    hipLaunchKernelGGL((smooth_slide_kernel<RB, NY, NIT, SW>), g2, dim3(64 * SW), lds, stream, (const float*)mid, P, P, w, r, dst, rects, h, h + r, 1);
+    return MA_OK;
 }
 
-static void smooth_planes(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r,
-                          const DzRect* rects, int h, DzSpan span)
+// one smoothing pass pair (y, then x) of `planes` planes of P x P: src -> mid (transposed) -> dst.  h: halo the input has
+// accumulated; span: largest content extent.  A wave issues one arithmetic instruction every ~8 cycles on its own and the SIMD
+// one every ~5 with two or more (tools/ubench_valu): a launch that would not put two long-running waves on every SIMD
+// is cut into four times as many short ones (NIT = 1: NY outputs per thread instead of 4 NY).
+template <int RB, int NY, int NIT>
+static int smooth_pair(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r,
+                       const DzRect* rects, int h, DzSpan span)
 {
-    if (r <= 12) smooth_pair<12, 16, 4>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
-    else if (r <= 18) smooth_pair<18, 16, 4>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
-    else if (r <= 24) smooth_pair<24, 16, 4>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
-    else if (r <= 40) smooth_pair<40, 8, 8>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
-    else {   // any radius: a thread per output, every tap from memory
-        const int in_h = std::min(P, span.h + 2 * h), in_w = std::min(P, span.w + 2 * h);
-        const int out_h = std::min(P, in_h + 2 * r), out_w = std::min(P, in_w + 2 * r);
-        hipLaunchKernelGGL((smooth_axis_rect_kernel<false>), dim3((in_w + 255) / 256, out_h, planes), dim3(256), 0, stream, src, P, w,
-                           r, mid, rects, h, h);
-        hipLaunchKernelGGL((smooth_axis_rect_kernel<true>), dim3((out_w + 255) / 256, out_h, planes), dim3(256), 0, stream,
-                           (const float*)mid, P, w, r, dst, rects, h + r, h);
-    }
+    const int in_h = std::min(P, span.h + 2 * h), in_w = std::min(P, span.w + 2 * h);
+    const int out_h = std::min(P, in_h + 2 * r), out_w = std::min(P, in_w + 2 * r);
+    const long long waves = (long long)((in_w + ST_B - 1) / ST_B) * ((out_h + NY * NIT - 1) / (NY * NIT)) * planes;
+    if (NIT > 1 && waves < 3 * 1024) return smooth_pair_launch<RB, NY, 1, 4>(stream, src, mid, dst, P, planes, w, r, rects, h, in_h, in_w, out_h, out_w);
+    return smooth_pair_launch<RB, NY, NIT, 4>(stream, src, mid, dst, P, planes, w, r, rects, h, in_h, in_w, out_h, out_w);
+}
+
+static int smooth_planes(hipStream_t stream, const float* src, float* mid, float* dst, int P, int planes, const double* w, int r,
+                         const DzRect* rects, int h, DzSpan span)
+{
+    // NY * NIT outputs per thread wait in registers for the transposition: 32 of them leave room for two waves per SIMD
+    if (r <= 12) return smooth_pair<12, 16, 2>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
+    if (r <= 18) return smooth_pair<18, 16, 2>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
+    if (r <= 24) return smooth_pair<24, 16, 2>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
+    if (r <= 40) return smooth_pair<40, 8, 4>(stream, src, mid, dst, P, planes, w, r, rects, h, span);
+    // any radius: a thread per output, every tap from memory
+    const int in_h = std::min(P, span.h + 2 * h), in_w = std::min(P, span.w + 2 * h);
+    const int out_h = std::min(P, in_h + 2 * r), out_w = std::min(P, in_w + 2 * r);
+    hipLaunchKernelGGL((smooth_axis_rect_kernel<false>), dim3((in_w + 255) / 256, out_h, planes), dim3(256), 0, stream, src, P, w,
+                       r, mid, rects, h, h);
+    hipLaunchKernelGGL((smooth_axis_rect_kernel<true>), dim3((out_w + 255) / 256, out_h, planes), dim3(256), 0, stream,
+                       (const float*)mid, P, w, r, dst, rects, h + r, h);
+    return MA_OK;
 }
 
 // Daisy.compute: one thread per (keypoint, histogram location); 25 locations x 8 orientation bins = 200 floats.
@@ -651,7 +712,7 @@ int daisy_enqueue(ma_ctx* ctx, const void* tiles, int dtype, int nt, int P, cons
         // scipy filters axis 1 (y) first, then axis 2 (x), each pass rounding to float32.  The intermediate of the two
         // passes lives in the next cube's slot (not yet written) or, for the last cube, in the layer buffer (done with)
         float* mid = c < 2 ? cubes + (c + 1) * cube : tmp;
-        smooth_planes(ctx->stream, src, mid, dst, P, nt * 8, tb.dev + tb.woff[c], radii[c], rects, h, span);
+        MA_TRY(smooth_planes(ctx->stream, src, mid, dst, P, nt * 8, tb.dev + tb.woff[c], radii[c], rects, h, span));
         h += radii[c];
         halo[c] = h;
         src = dst;

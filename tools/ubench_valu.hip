@@ -12,6 +12,9 @@ __global__ void k(float* out, int iters, float seed)
     float a[8];
     float2v p[8];
     for (int i = 0; i < 8; i++) { a[i] = seed + i + threadIdx.x; p[i] = (float2v){a[i], a[i] + 1.f}; }
+    double d[8];
+    for (int i = 0; i < 8; i++) d[i] = (double)a[i];
+    const double db = 1.0 + 1e-9 * seed;
     float b = seed * 0.5f + 1.0f;
     float2v pb = {b, b};
     for (int it = 0; it < iters; it++) {
@@ -25,10 +28,13 @@ __global__ void k(float* out, int iters, float seed)
             if (MODE == 5) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[u]) : "v"(pb));
             if (MODE == 6) asm volatile("v_mov_b32 %0, %1" : "+v"(a[u]) : "v"(b));
             if (MODE == 7) asm volatile("v_mov_b64 %0, %1" : "+v"(p[u]) : "v"(pb));
+            if (MODE == 8) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[u]) : "v"(db));
+            if (MODE == 9) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[u]) : "v"(db));
+            if (MODE == 10) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(d[u]) : "v"(db));
         }
     }
     float s = 0;
-    for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y;
+    for (int i = 0; i < 8; i++) s += a[i] + p[i].x + p[i].y + (float)d[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -61,7 +67,7 @@ void run(const char* name, int waves_per_simd, float lanes_per_instr)
 
 int main()
 {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {1, 2, 3, 4, 8}) {
         run<0>("v_fma_f32", w, 1);
         run<1>("v_add_f32", w, 1);
         run<2>("v_mul_f32", w, 1);
@@ -70,6 +76,9 @@ int main()
         run<5>("v_pk_mul_f32", w, 2);
         run<6>("v_mov_b32", w, 1);
         run<7>("v_mov_b64", w, 2);
+        run<8>("v_add_f64", w, 1);
+        run<9>("v_mul_f64", w, 1);
+        run<10>("v_fma_f64", w, 1);
     }
     return 0;
 }
