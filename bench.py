@@ -495,6 +495,128 @@ def host_stream_leg(n_pairs, ref, mov, params, dtype):
                     "arrays in input order"}
 
 
+HOST_MODES = ("stream_pairs_pageable", "stream_pairs_page_locked", "warp_pages_pageable", "warp_pages_page_locked")
+
+
+def host_modes_measure(ctx, ref, mov, params, n_pairs, n_pages, sync):
+    """The numpy -> numpy modes of DESIGN.md section 6 on THIS rank, each between two barriers (`sync`) so that every rank of
+    the node runs the same mode at the same time -- these, not the device-resident headline, are what can fail to scale: the
+    staged path makes three to four passes over host DRAM per payload byte.  Per mode: units, seconds (fill and drain of the
+    pipeline included), payload bytes in + out, and whether the library moved the caller's buffers by DMA as they are
+    (`direct_*`, the library's own decision: ma_host_transfer_is_direct).
+      stream_pairs_*: parallel.stream_pairs over `n_pairs` pairs (two distinct pairs alternating), flow + warped image into
+                      caller arrays; *_pageable: plain numpy arrays in and out; *_page_locked: the same arrays page-locked in
+                      place (device.host_register; its cost is reported as host_register_ms_per_gib);
+      warp_pages_*  : Warper.warp_pages, one resident flow over `n_pages` uint16 pages, pageable / page-locked."""
+    import numpy as np
+    from microaligner_amd import Warper, device, parallel
+    H, W = ref.shape
+    res = {}
+    ins = [(ref, mov), (np.roll(ref, 53, axis=0), np.roll(mov, 53, axis=0))]
+    outs = [(np.zeros((H, W, 2), np.float32), np.zeros((H, W), ref.dtype)) for _ in range(2)]      # touched: no page faults timed
+    seq = [ins[k % 2] for k in range(n_pairs)]
+
+    def guarded(tag, fn):
+        # every rank passes the same barriers whatever happens to it in between: a failure becomes the mode's row
+        try:
+            return fn()
+        except Exception as e:   # noqa: BLE001
+            res.setdefault(tag, {})["error"] = repr(e)
+            return None
+
+    def stream(tag):
+        def warm():
+            for _ in parallel.stream_pairs(seq[:2], params, warp=True, out=lambda i: outs[i % 2]):   # slots, rings, copy threads
+                pass
+
+        def timed():
+            ctx.transfer_stats(reset=True)
+            t0 = time.perf_counter()
+            for _ in parallel.stream_pairs(seq, params, warp=True, out=lambda i: outs[i % 2]):
+                pass
+            dt = time.perf_counter() - t0
+            up, down = ctx.transfer_stats(reset=True)
+            res[tag] = {"units": n_pairs, "unit": "pair", "seconds": dt, "payload_bytes": int(up + down),
+                        "direct_in": device.transfer_is_direct(ins[0][0]), "direct_out": device.transfer_is_direct(outs[0][0])}
+        guarded(tag, warm)
+        sync()
+        guarded(tag, timed)
+        sync()
+
+    stream("stream_pairs_pageable")
+    t0 = time.perf_counter()
+    locked = [a for pair in ins + outs for a in pair]
+    ok = all([device.host_register(a) for a in locked])
+    reg_s = time.perf_counter() - t0
+    stream("stream_pairs_page_locked")
+    res.setdefault("stream_pairs_page_locked", {})["registered_in_place"] = ok
+    res["host_register_ms_per_gib"] = round(reg_s * 1e3 / (sum(a.nbytes for a in locked) / 2 ** 30), 1)
+    for a in locked:
+        device.host_unregister(a)
+    flow_host = outs[0][0]
+    del ins, seq, locked
+
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 65535, (H, W), dtype=np.uint16)
+    pages = [base ^ np.uint16(257 * k) for k in range(n_pages)]
+    pout = [np.ones_like(base) for _ in range(n_pages)]
+    w = Warper()
+    w.tile_size, w.overlap = params.get("tile_size", 1000), params.get("overlap", 100)
+    w.flow = ctx.asdevice(flow_host)          # the flow of the last streamed pair
+    del outs, flow_host
+
+    def paged(tag):
+        def timed():
+            ctx.transfer_stats(reset=True)
+            t0 = time.perf_counter()
+            w.warp_pages(pages, pout)
+            dt = time.perf_counter() - t0
+            up, down = ctx.transfer_stats(reset=True)
+            res[tag] = {"units": n_pages, "unit": "uint16 page", "seconds": dt, "payload_bytes": int(up + down),
+                        "direct_in": device.transfer_is_direct(pages[0]), "direct_out": device.transfer_is_direct(pout[0])}
+        guarded(tag, lambda: w.warp_pages(pages[:2], pout[:2]))
+        sync()
+        guarded(tag, timed)
+        sync()
+
+    paged("warp_pages_pageable")
+    ok = all([device.host_register(a) for a in pages + pout])
+    paged("warp_pages_page_locked")
+    res.setdefault("warp_pages_page_locked", {})["registered_in_place"] = ok
+    for a in pages + pout:
+        device.host_unregister(a)
+    return res
+
+
+def host_modes_report(rows, H, W):
+    """Rank 0: every rank's host-mode rows -> per mode the per-rank times, the whole-node rate (all units / the slowest rank's
+    time) and the whole-node payload rate over PCIe (the staged path moves 3 - 4 times that through host DRAM)."""
+    out = {}
+    for mode in HOST_MODES:
+        per = [r.get(mode) for r in rows]
+        if any(p is None for p in per):
+            continue
+        if any("seconds" not in p for p in per):
+            out[mode] = {"error": [p.get("error") for p in per]}
+            continue
+        slowest = max(p["seconds"] for p in per)
+        units = sum(p["units"] for p in per)
+        out[mode] = {"unit": per[0]["unit"], "units_per_rank": per[0]["units"],
+                     "ms_per_unit_per_rank": [round(p["seconds"] / p["units"] * 1e3, 2) for p in per],
+                     "aggregate_mpix_s": round(units * H * W / slowest / 1e6, 1),
+                     "aggregate_payload_gb_s": round(sum(p["payload_bytes"] for p in per) / slowest / 1e9, 1),
+                     "buffers_moved_directly": [bool(p["direct_in"] and p["direct_out"]) for p in per]}
+        if "registered_in_place" in per[0]:
+            out[mode]["registered_in_place"] = [bool(p["registered_in_place"]) for p in per]
+    reg = [r.get("host_register_ms_per_gib") for r in rows if r.get("host_register_ms_per_gib") is not None]
+    if reg:
+        out["host_register_ms_per_gib"] = reg
+    out["what"] = ("every rank runs the same numpy -> numpy mode at the same time (barriers on both sides); seconds include "
+                   "filling and draining the pipeline once; aggregate_* = all ranks' units (bytes) / the slowest rank's time; "
+                   "DESIGN.md section 6 gives the host DRAM passes behind each mode")
+    return out
+
+
 # ---- launcher ----------------------------------------------------------------------------------------------
 def free_port():
     s = socket.socket()
@@ -591,6 +713,13 @@ def main():
     ap.add_argument("--pairs-total", type=int, default=0,
                     help="a step is one pass over K independent pairs dealt round-robin to the ranks (BASELINE cfg4: 8 "
                          "cycle pairs, cfg5: 64 mosaic tiles) instead of one pair per rank; scaling is then strong")
+    ap.add_argument("--host-modes", default="auto", choices=["auto", "on", "off"],
+                    help="after the timed loop every rank runs the numpy -> numpy modes (parallel.stream_pairs and "
+                         "Warper.warp_pages, pageable and page-locked buffers) at the same time and the line reports them per "
+                         "rank with the whole-node rates (`host_modes`); auto: when N > 1 -- the modes that can fail to "
+                         "scale -- at N = 1 the `variants` legs cover them")
+    ap.add_argument("--host-mode-pairs", type=int, default=4, help="pairs per rank of the stream_pairs host modes")
+    ap.add_argument("--host-mode-pages", type=int, default=4, help="uint16 pages per rank of the warp_pages host modes")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduce plumbing only, no GPU work (CPU test of the N-rank launcher)")
     args = ap.parse_args()
@@ -659,8 +788,19 @@ def main():
         parallel.run_sharded([loader(i) for i in range(n_units)], lambda u: np.full((4, 8), 1000 * rank + u, np.float32),
                              out=store)
         shared_ok = bool(all(np.all(store[i] == 1000 * (i % world) + i) for i in range(n_units)))
-        rows = rank_table(dist, world, rank, {"rank": rank, "ms_per_step": mine / args.steps * 1e3, "pairs": my_pairs,
-                                               "device": None, "pci_bus_id": None, "units_loaded": sorted(loaded)})
+        row = {"rank": rank, "ms_per_step": mine / args.steps * 1e3, "pairs": my_pairs,
+               "device": None, "pci_bus_id": None, "units_loaded": sorted(loaded)}
+        want_modes = args.host_modes == "on" or (args.host_modes == "auto" and world > 1)
+        if want_modes:       # the plumbing of the host-mode rows (barriers, gather, report) with made-up times
+            for k, mode in enumerate(HOST_MODES):
+                if dist is not None:
+                    dist.barrier()
+                n = args.host_mode_pairs if mode.startswith("stream") else args.host_mode_pages
+                row[mode] = {"units": n, "unit": "pair" if mode.startswith("stream") else "uint16 page",
+                             "seconds": 1e-3 * n * (k + 1) * (1 + 0.01 * rank), "payload_bytes": 1000 * n,
+                             "direct_in": mode.endswith("locked"), "direct_out": mode.endswith("locked")}
+            row["host_register_ms_per_gib"] = 100.0
+        rows = rank_table(dist, world, rank, row)
         if rank == 0:
             per = [r["ms_per_step"] for r in rows]
             print(json.dumps({"metric": METRIC, "value": None, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps,
@@ -668,6 +808,7 @@ def main():
                               "config": {"workload": args.workload, "pairs_per_step": pairs_per_step},
                               "ranks": rows, "results_via": "shared memory array written in place by the owning rank",
                               "shared_results_ok": shared_ok,
+                              "host_modes": host_modes_report(rows, 1000, 1000) if want_modes else None,
                               "rank_ms_per_step": {"min": min(per), "mean": sum(per) / len(per), "max": max(per)}}))
         if dist is not None:
             dist.barrier()
@@ -717,7 +858,8 @@ def main():
             ref, mov = synthetic.make_pair(H, W, seed=1 + idx, dtype=np_dtype)
         work.append((ctx.asdevice(ref), ctx.asdevice(mov), inv_affine, host))
     keep_host = world == 1 and not args.no_variants and not args.pairs_total
-    if not keep_host and freg is None:
+    want_modes = (args.host_modes == "on" or (args.host_modes == "auto" and world > 1)) and not wl.get("affine")
+    if not keep_host and freg is None and not want_modes:
         ref = mov = None
     ctx.forget_host_arrays()
 
@@ -814,8 +956,19 @@ def main():
             del flows, warps
         else:
             shared_note = f"skipped: /dev/shm has {room / 2 ** 30:.0f} GiB free, {need / 2 ** 30:.0f} GiB needed"
+    host_rows = {}
+    if want_modes and out is not None:
+        del out
+        out = None
+        ctx.trim()        # the headline's pooled buffers go back: the stream needs its own slots and lanes
+        try:
+            host_rows = host_modes_measure(ctx, ref, mov, params, args.host_mode_pairs, args.host_mode_pages,
+                                           (dist.barrier if dist is not None else (lambda: None)))
+        except Exception as e:   # noqa: BLE001 -- never at the cost of the headline; but every rank must leave the barriers
+            import traceback
+            host_rows = {"host_modes_error": repr(e) + " | " + traceback.format_exc().strip().splitlines()[-1]}
     info = device_info(dev_index)
-    rows = rank_table(dist, world, rank, {
+    rows = rank_table(dist, world, rank, {**host_rows, 
         "rank": rank, "device": dev_index, "pci_bus_id": info["pci_bus_id"], "name": info["name"],
         "hbm_free_gb": round(info["mem_free"] / 2 ** 30, 1), "hbm_total_gb": round(info["mem_total"] / 2 ** 30, 1),
         "cpus": (f"{cpu_ranges(bound_cpus)} ({len(bound_cpus)} of {len(all_cpus)}, local to the device)"
@@ -823,7 +976,7 @@ def main():
         "pairs": my_pairs, "ms_per_step": round((t1 - t0) / args.steps * 1e3, 3), "clock_ghz": round(clock_ghz, 3),
         "result": summary})
     gather_ms = (time.perf_counter() - tg0) * 1e3
-    del out
+    out = None
 
     if rank == 0:
         prof = ctx.profile_get()
@@ -879,6 +1032,12 @@ def main():
             "results_to_shared_array_ms": round(shared_ms, 1) if shared_ms is not None else None,
             "results_to_shared_array": shared_note,
         }
+        if want_modes:
+            errs = [r["host_modes_error"] for r in rows if "host_modes_error" in r]
+            res["host_modes"] = {"error": errs} if errs else host_modes_report(rows, H, W)
+            for r in rows:       # the per-rank rows stay compact: the modes are reported above
+                for k in HOST_MODES + ("host_register_ms_per_gib", "host_modes_error"):
+                    r.pop(k, None)
         def informational(store, name, fn):
             """An informational leg never costs the headline line: a failure is recorded in its place."""
             try:

@@ -431,11 +431,13 @@ class Context:
         this copy is complete (the compute stream is not involved: order it with engine_record / engine_wait)."""
         if arr.nbytes != dst.nbytes or not arr.flags.c_contiguous:
             raise ValueError("engine_upload needs a C-contiguous host array of the device array's size")
+        _warn_if_staged_on_a_full_node(arr)
         L.check(self.lib.ma_engine_memcpy_h2d(self.handle, int(engine), dst.ptr, arr.ctypes.data, arr.nbytes))
 
     def engine_download(self, src, out, engine=L.MA_ENGINE_D2H):
         if out.nbytes != src.nbytes or not out.flags.c_contiguous:
             raise ValueError("engine_download needs a C-contiguous host array of the device array's size")
+        _warn_if_staged_on_a_full_node(out)
         L.check(self.lib.ma_engine_memcpy_d2h(self.handle, int(engine), out.ctypes.data, src.ptr, out.nbytes))
 
     def engine_record(self, engine, ev):
@@ -1061,27 +1063,68 @@ def host_register(arr):
     """Page-lock `arr`'s memory in place (ma_host_register): transfers to and from it then go by DMA directly instead of
     through the staging chunks -- one pass over host DRAM per byte instead of three.  For arrays that live across many
     transfers (parallel.shared_array results, reused input buffers); registration itself costs about a first touch of
-    every page.  Returns True when the range is page-locked now, False when the runtime refused (no device in this
-    process, pages that cannot be pinned -- a memmap of a file on disk): the array then goes through the staging path as
-    before.  The registration ends with the array (weakref finalizer)."""
+    every page.  Returns True when the range is page-locked now, False when nothing was registered: the runtime refused
+    (no device in this process, pages that cannot be pinned -- a memmap of a file on disk), or `arr` is not an ndarray /
+    memmap whose memory outlives the call (a list would be converted to a temporary, and a registration must never outlive
+    its memory), or no finalizer can be attached to the object that owns the memory.  The array then goes through the
+    staging path as before.  The registration ends with the array (weakref finalizer on its owner)."""
     import weakref
-    a = np.asarray(arr)
-    if a.nbytes == 0 or not a.flags.c_contiguous:
-        return False
-    lib = L.load()
-    ptr = a.ctypes.data
-    if lib.ma_host_register(C.c_void_p(ptr), C.c_size_t(a.nbytes)) != L.MA_OK:
+    if not isinstance(arr, np.ndarray) or arr.nbytes == 0 or not arr.flags.c_contiguous:
         return False
     base = arr
     while isinstance(getattr(base, "base", None), np.ndarray):     # the finalizer hangs on the object that owns the memory
         base = base.base
+    lib = L.load()
+    ptr = arr.ctypes.data
+    if lib.ma_host_register(C.c_void_p(ptr), C.c_size_t(arr.nbytes)) != L.MA_OK:
+        return False
     try:
         # (the finalizer must run BEFORE the memory is unmapped: it hangs on the owning ndarray / memmap, whose death precedes
         # the release of its buffer)
         weakref.finalize(base, lib.ma_host_unregister, C.c_void_p(ptr))
-    except TypeError:                                                # not weak-referenceable: stays registered
-        pass
+    except TypeError:          # not weak-referenceable: nothing would ever end the registration
+        lib.ma_host_unregister(C.c_void_p(ptr))
+        return False
     return True
+
+
+def host_unregister(arr):
+    """End a registration made by host_register(arr) now (its finalizer later finds nothing left to do)."""
+    if isinstance(arr, np.ndarray) and arr.nbytes:
+        return L.load().ma_host_unregister(C.c_void_p(arr.ctypes.data)) == L.MA_OK
+    return False
+
+
+def transfer_is_direct(arr):
+    """Whether a transfer to / from the whole of `arr` goes by DMA as it is (page-locked over its full extent) or through
+    the staging ring (ma_host_transfer_is_direct)."""
+    a = np.asarray(arr)
+    if a.nbytes == 0:
+        return False
+    out = C.c_int(0)
+    L.check(L.load().ma_host_transfer_is_direct(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), C.byref(out)))
+    return bool(out.value)
+
+
+_STAGED_WARNED = [False]
+
+
+def _warn_if_staged_on_a_full_node(arr):
+    """beyond about three ranks per node the staged path (three to four passes over host DRAM per
+    payload byte) cannot be the data plane.  Said once per process when a big pageable array reaches a transfer engine."""
+    if _STAGED_WARNED[0] or arr.nbytes < (64 << 20):
+        return
+    try:
+        ws = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    except ValueError:
+        return
+    if ws >= 3 and not transfer_is_direct(arr):
+        import warnings
+        _STAGED_WARNED[0] = True
+        warnings.warn(f"microaligner_amd: a pageable {arr.nbytes >> 20} MiB array is going through the staged copy path with "
+                      f"{ws} ranks on this node; the host's memory bandwidth will not carry that for every rank -- page-lock "
+                      "buffers that are reused (device.host_register, parallel.shared_array, Context.host_empty)",
+                      RuntimeWarning, stacklevel=3)
 
 
 def device_count():

@@ -117,9 +117,12 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: b
     into the shared memory -- no staging copy: per result byte one pass over host DRAM instead of three, which is what keeps
     eight ranks within the host's memory bandwidth.  page_locked="all": the whole array (a rank that
     writes rows of its own choosing).  Where the runtime refuses (no device: gloo tests, --dry-run; a file on disk) the
-    array is pageable as before; `arr_is_page_locked(arr)` tells."""
+    array is pageable as before; `arr_is_page_locked(arr)` tells.  MICROALIGNER_SHARED_PAGE_LOCK=0 in the environment turns
+    the default off (hosts with a memlock limit: pinning makes a sparse /dev/shm file resident)."""
     import numpy as np
     rank, ws = world()
+    if page_locked is True and os.environ.get("MICROALIGNER_SHARED_PAGE_LOCK", "1") == "0":
+        page_locked = False       # hosts with a memlock limit: the default can be switched off from outside
     # SINGLE NODE: the file is created once and every rank maps that one file.  A launch that spans nodes has ranks whose
     # /dev/shm is another machine's -- refuse it rather than fail in np.load after the barrier.
     local_ws = int(os.environ.get("LOCAL_WORLD_SIZE", ws))
@@ -153,19 +156,26 @@ _PAGE_LOCKED = {}      # id(memmap) -> True, dropped with the array
 
 def _page_lock(arr, pieces):
     """Best effort: only where a device exists in this process (the registration needs the HIP runtime).  pieces: views of
-    `arr` (contiguous blocks) to register; the registrations end with `arr` (the views' finalizers hang on its buffer)."""
+    `arr` (contiguous blocks) to register; the registrations end with `arr` (the views' finalizers hang on its buffer).
+    All or nothing: when one piece cannot be registered the ones before it are released again, so that
+    arr_is_page_locked() never says False about an array that is partly pinned."""
     try:
         from . import device
         if device.device_count() <= 0 or not pieces:
             return False
-        ok = all([device.host_register(p) for p in pieces])
+        done = []
+        for p in pieces:
+            if not device.host_register(p):
+                for q in done:
+                    device.host_unregister(q)
+                return False
+            done.append(p)
     except Exception:   # noqa: BLE001 -- no library / no device: the staging path serves the array
         return False
-    if ok:
-        import weakref
-        _PAGE_LOCKED[id(arr)] = True
-        weakref.finalize(arr, _PAGE_LOCKED.pop, id(arr), None)
-    return ok
+    import weakref
+    _PAGE_LOCKED[id(arr)] = True
+    weakref.finalize(arr, _PAGE_LOCKED.pop, id(arr), None)
+    return True
 
 
 def arr_is_page_locked(arr) -> bool:

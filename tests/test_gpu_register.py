@@ -933,3 +933,28 @@ def test_a_copy_that_runs_past_a_page_locked_range_is_staged(ctx):
     assert direct(pinned.ctypes.data, pinned.nbytes) == 1
     assert direct(pinned.ctypes.data, 64 << 20) == 0
     del pinned
+
+
+def test_two_ranks_download_into_their_own_page_locked_rows(tmp_path):
+    """parallel.shared_array with more than one rank: every rank page-locks the rows shard() deals to it, in its own mapping,
+    one registration per row; downloads into own rows go by DMA as they are, a range that runs into a foreign row is staged,
+    everybody sees everybody's rows.  Two processes over gloo sharing the box's device (tests/_dist_gpu_worker.py)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "res.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "_dist_gpu_worker.py"), str(out)],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.load(open(out))
+    assert [row["rank"] for row in res] == [0, 1]
+    for row in res:
+        assert row["ok"] and row["locked"]
+        assert all(row["direct_own"]) and not any(row["direct_other"]) and row["direct_span"] is False

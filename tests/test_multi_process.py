@@ -57,6 +57,8 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 3 and res["config"]["pairs_per_step"] == 2
+    assert set(res["host_modes"]) >= {"stream_pairs_pageable", "stream_pairs_page_locked", "warp_pages_pageable",
+                                      "warp_pages_page_locked"}
 
 
 def test_bench_eight_ranks_report_per_rank_rows_and_deal_pairs_round_robin():
@@ -80,6 +82,17 @@ def test_bench_eight_ranks_report_per_rank_rows_and_deal_pairs_round_robin():
     per = [row["ms_per_step"] for row in res["ranks"]]
     assert res["rank_ms_per_step"] == {"min": min(per), "mean": sum(per) / 8, "max": max(per)}
     assert abs(res["ms_per_step"] - max(per)) < 1e-9            # the headline time is the slowest rank's
+    # the numpy -> numpy modes (the ones that can fail to scale) are part of every N > 1 line: per mode one
+    # time per rank, the whole-node rates from the slowest rank, and whether the library moved the buffers by DMA as they are
+    hm = res["host_modes"]
+    for mode in ("stream_pairs_pageable", "stream_pairs_page_locked", "warp_pages_pageable", "warp_pages_page_locked"):
+        row = hm[mode]
+        assert len(row["ms_per_unit_per_rank"]) == 8 and len(row["buffers_moved_directly"]) == 8
+        assert row["aggregate_mpix_s"] > 0 and row["units_per_rank"] == 4
+        assert row["buffers_moved_directly"] == [mode.endswith("locked")] * 8
+        slowest = max(row["ms_per_unit_per_rank"]) * row["units_per_rank"] / 1e3
+        assert row["aggregate_mpix_s"] == pytest.approx(8 * row["units_per_rank"] * 1e6 / slowest / 1e6, rel=1e-2)
+    assert len(hm["host_register_ms_per_gib"]) == 8
 
 
 def test_bench_launcher_propagates_a_rank_failure():
