@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256) void warp_affine_cv_kernel(const T* __restrict
 // ---- Warper.warp(): window-local map = float(x_local) - flow, window-local constant border ----
 // A tap contributes iff it lies inside the window [0,P) AND inside the image (the window is the
 // zero-padded crop slicer.py builds); both cases read as 0, exactly what cv2.remap sees.
+// Nearly every pixel has all four taps inside both: one compound test, one 32-bit element index and three constant
+// offsets from it (IDX32: the image has fewer than 2^31 elements, uniform per launch); the pixels at window and image
+// borders take the tap-by-tap form.
 template <typename T>
 __device__ __forceinline__ T warp_tiled_px(const T* __restrict__ img, const MaTiling& g, float2 f, int x, int y, int oy,
                                            int ox)
@@ -158,15 +161,79 @@ __device__ __forceinline__ T warp_tiled_px(const T* __restrict__ img, const MaTi
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             int sx = t.sx + (k & 1), sy = t.sy + (k >> 1);
-            int ix = ox + sx, iy = oy + sy;
-            bool ok = sx >= 0 && sx < g.Pw && sy >= 0 && sy < g.Ph && (unsigned)ix < (unsigned)g.W &&
-                      (unsigned)iy < (unsigned)g.H;
-            v[k] = ok ? img[(size_t)iy * g.W + ix] : (T)0;
+            int jx = ox + sx, jy = oy + sy;
+            bool ok = sx >= 0 && sx < g.Pw && sy >= 0 && sy < g.Ph && (unsigned)jx < (unsigned)g.W &&
+                      (unsigned)jy < (unsigned)g.H;
+            v[k] = ok ? img[(size_t)jy * g.W + jx] : (T)0;
         }
         res = Interp<T>::run(v[0], v[1], v[2], v[3], t.fx, t.fy);
     }
     return res;
 }
+
+// R rows of one column.  Nearly every thread has all four taps of all its rows inside both the window and the image: then
+// (a wave-wide vote, so that the code stays straight-line and the loads of all rows are issued before the first result is
+// computed) a tap is one 32-bit element index and three constant offsets from it, with no per-tap test (IDX32: the image
+// has fewer than 2^31 elements, uniform per launch); waves that touch a window or image border take the tap-by-tap form.
+template <typename T, bool IDX32, int R>
+__device__ __forceinline__ void warp_tiled_rows(const T* __restrict__ img, const MaTiling& g, const float2 (&f)[R], int x,
+                                                const int (&y)[R], const int (&oy)[R], int ox, T (&res)[R])
+{
+    Tap t[R];
+    bool inside = true;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        t[r] = quantise((float)(x - ox) - f[r].x, (float)(y[r] - oy[r]) - f[r].y);
+        inside = inside && (unsigned)t[r].sx < (unsigned)(g.Pw - 1) && (unsigned)t[r].sy < (unsigned)(g.Ph - 1) &&
+                 (unsigned)(ox + t[r].sx) < (unsigned)(g.W - 1) && (unsigned)(oy[r] + t[r].sy) < (unsigned)(g.H - 1);
+    }
+    if (__all(inside)) {
+        T v[R][4];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (IDX32) {
+                const unsigned p = (unsigned)(oy[r] + t[r].sy) * (unsigned)g.W + (unsigned)(ox + t[r].sx);
+                v[r][0] = img[p]; v[r][1] = img[p + 1]; v[r][2] = img[p + (unsigned)g.W]; v[r][3] = img[p + (unsigned)g.W + 1];
+            } else {
+                const T* q = img + (size_t)(oy[r] + t[r].sy) * g.W + (ox + t[r].sx);
+                v[r][0] = q[0]; v[r][1] = q[1]; v[r][2] = q[g.W]; v[r][3] = q[g.W + 1];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) res[r] = Interp<T>::run(v[r][0], v[r][1], v[r][2], v[r][3], t[r].fx, t[r].fy);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) res[r] = warp_tiled_px<T>(img, g, f[r], x, y[r], oy[r], ox);
+    }
+}
+
+// Window origin along x of column `x` (ox = (x / T) T - ov) without a division per lane: the 64 columns of a wave lie in at
+// most two windows when T >= 64 -- the wave's first column decides (a scalar division), the columns at or beyond the next
+// window's first take that one.
+__device__ __forceinline__ int warp_window_origin_x(int x, const MaTiling& g)
+{
+    if (g.T <= 0) return 0;
+    if (g.T < 64) return (x / g.T) * g.T - g.ov;
+    const int x_first = __builtin_amdgcn_readfirstlane(x - (int)(threadIdx.x & 63));
+    const int t0 = x_first / g.T, next = (t0 + 1) * g.T;
+    return (x >= next ? next : t0 * g.T) - g.ov;
+}
+// Window origins along y of the rows y0 .. y0 + R of a block: one division, the rows at or beyond the next window's first
+// row take that one (T >= R; smaller tiles divide per row)
+struct WarpRowsY {
+    int t0T, next, T, ov;
+    __device__ __forceinline__ WarpRowsY(int y0, const MaTiling& g) : T(g.T), ov(g.ov)
+    {
+        const int t0 = g.T > 0 ? y0 / g.T : 0;
+        t0T = t0 * g.T; next = t0T + g.T;
+    }
+    __device__ __forceinline__ int origin(int y) const
+    {
+        if (T <= 0) return 0;
+        if (T < 16) return (y / T) * T - ov;
+        return (y >= next ? next : t0T) - ov;
+    }
+};
 
 // floats <-> unsigned keys whose integer order is the float order (so atomicMax works for any sign); every NaN maps
 // to the largest key, so it survives the atomic reduction (numpy's .max() propagates NaN)
@@ -202,7 +269,7 @@ constexpr int CELL_REPLICAS = MA_FLOW_CELL_REPLICAS;    // the public header siz
 // the registration merges passes through this kernel first (the pre-warp of a level reads the accumulated flow, the
 // gate's warp reads the level's flow), so _merge_flow_in_tiles' per-window .max() tests (optflow_registrator.py:
 // 38-42) need no pass of their own over the two flows.
-template <typename T, bool MM>
+template <typename T, bool MM, bool IDX32>
 __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ img, MaTiling g,
                                                          const float2* __restrict__ flow, T* __restrict__ out,
                                                          float* __restrict__ part, unsigned* __restrict__ cellkeys,
@@ -219,8 +286,9 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
 #pragma unroll
         for (int r = 0; r < WARP_ROWS; r++) ck_row[r] = 0u;
     }
+    const int ox = warp_window_origin_x(min(x, g.W - 1), g);      // (all lanes: the wave's first lane decides)
+    const WarpRowsY rows(y0, g);
     if (xin) {
-        const int ox = g.T > 0 ? (x / g.T) * g.T - g.ov : 0;
         float2 f[WR];
 #pragma unroll
         for (int r = 0; r < WR; r++) f[r] = flow[(size_t)min(y0 + r, g.H - 1) * g.W + x];
@@ -230,12 +298,10 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
             ck_sx = d_segment(x, g.T, g.ov);
         }
         T res[WR];
+        int ys[WR], oys[WR];
 #pragma unroll
-        for (int r = 0; r < WR; r++) {
-            const int y = y0 + r;
-            const int oy = g.T > 0 ? (y / g.T) * g.T - g.ov : 0;
-            res[r] = warp_tiled_px<T>(img, g, f[r], x, min(y, g.H - 1), oy, ox);
-        }
+        for (int r = 0; r < WR; r++) { ys[r] = min(y0 + r, g.H - 1); oys[r] = rows.origin(y0 + r); }
+        warp_tiled_rows<T, IDX32, WR>(img, g, f, x, ys, oys, ox, res);
 #pragma unroll
         for (int r = 0; r < WR; r++)
             if (y0 + r < g.H) {
@@ -272,25 +338,24 @@ __global__ __launch_bounds__(256) void warp_tiled_kernel(const T* __restrict__ i
 }
 
 // the rows [y_begin, y_end) of warp_tiled_kernel's result (bands of the page-warp driver, ma_warp_pages_host)
-template <typename T>
+template <typename T, bool IDX32>
 __global__ __launch_bounds__(256) void warp_band_kernel(const T* __restrict__ img, MaTiling g,
                                                         const float2* __restrict__ flow, T* __restrict__ out,
                                                         int y_begin, int y_end)
 {
     constexpr int WR = WARP_ROWS;
     const int x = blockIdx.x * 256 + threadIdx.x, y0 = y_begin + blockIdx.y * WR;
+    const int ox = warp_window_origin_x(min(x, g.W - 1), g);
     if (x >= g.W) return;
-    const int ox = g.T > 0 ? (x / g.T) * g.T - g.ov : 0;
+    const WarpRowsY rows(y0, g);
     float2 f[WR];
 #pragma unroll
     for (int r = 0; r < WR; r++) f[r] = flow[(size_t)min(y0 + r, y_end - 1) * g.W + x];
     T res[WR];
+    int ys[WR], oys[WR];
 #pragma unroll
-    for (int r = 0; r < WR; r++) {
-        const int y = min(y0 + r, y_end - 1);
-        const int oy = g.T > 0 ? (y / g.T) * g.T - g.ov : 0;
-        res[r] = warp_tiled_px<T>(img, g, f[r], x, y, oy, ox);
-    }
+    for (int r = 0; r < WR; r++) { ys[r] = min(y0 + r, y_end - 1); oys[r] = rows.origin(ys[r]); }
+    warp_tiled_rows<T, IDX32, WR>(img, g, f, x, ys, oys, ox, res);
 #pragma unroll
     for (int r = 0; r < WR; r++)
         if (y0 + r < y_end) out[(size_t)(y0 + r) * g.W + x] = res[r];
@@ -533,12 +598,15 @@ static int warp_tiled_impl(ma_ctx* ctx, const void* img, int dtype, int H, int W
         MA_HIP(hipMemsetAsync(flow_cellkeys_dev, 0, (size_t)CELL_REPLICAS * nsegx * nsegy * sizeof(unsigned), ctx->stream));
     const float2* f = (const float2*)flow;
     unsigned* ck = flow_cellkeys_dev;
-#define MA_WARP(T) do { if (part) hipLaunchKernelGGL((warp_tiled_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part, ck, nsegx, nsegy); \
-                        else hipLaunchKernelGGL((warp_tiled_kernel<T, false>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part, ck, nsegx, nsegy); } while (0)
+    const bool idx32 = (unsigned long long)H * (unsigned long long)W < (1ull << 31);
+#define MA_WARP2(T, MMF, IX) hipLaunchKernelGGL((warp_tiled_kernel<T, MMF, IX>), grid, block, 0, ctx->stream, (const T*)img, g, f, (T*)out, part, ck, nsegx, nsegy)
+#define MA_WARP(T) do { if (part) { if (idx32) MA_WARP2(T, true, true); else MA_WARP2(T, true, false); } \
+                        else { if (idx32) MA_WARP2(T, false, true); else MA_WARP2(T, false, false); } } while (0)
     if (dtype == MA_U8) MA_WARP(uint8_t);
     else if (dtype == MA_U16) MA_WARP(uint16_t);
     else MA_WARP(float);
 #undef MA_WARP
+#undef MA_WARP2
     MA_HIP(hipGetLastError());
     if (part) MA_TRY(ma_launch_minmax_final(ctx, part, (int)nblk, minmax_dev));
     return MA_OK;
@@ -734,9 +802,13 @@ int ma_warp_pages_host(ma_ctx* ctx, const void* const* pages_host, void* const* 
         const dim3 grid((W + 255) / 256, (y1 - y0 + WARP_ROWS - 1) / WARP_ROWS);
         hipError_t e = hipStreamWaitEvent(ctx->stream, ev_up[(size_t)k * nband + b], 0);
         if (e == hipSuccess) {
-            if (dtype == MA_U8) hipLaunchKernelGGL((warp_band_kernel<uint8_t>), grid, block, 0, ctx->stream, (const uint8_t*)din[k], g, f, (uint8_t*)dout[k], y0, y1);
-            else if (dtype == MA_U16) hipLaunchKernelGGL((warp_band_kernel<uint16_t>), grid, block, 0, ctx->stream, (const uint16_t*)din[k], g, f, (uint16_t*)dout[k], y0, y1);
-            else hipLaunchKernelGGL((warp_band_kernel<float>), grid, block, 0, ctx->stream, (const float*)din[k], g, f, (float*)dout[k], y0, y1);
+#define MA_BAND(T) do { if (idx32) hipLaunchKernelGGL((warp_band_kernel<T, true>), grid, block, 0, ctx->stream, (const T*)din[k], g, f, (T*)dout[k], y0, y1); \
+                        else hipLaunchKernelGGL((warp_band_kernel<T, false>), grid, block, 0, ctx->stream, (const T*)din[k], g, f, (T*)dout[k], y0, y1); } while (0)
+            const bool idx32 = (unsigned long long)H * (unsigned long long)W < (1ull << 31);
+            if (dtype == MA_U8) MA_BAND(uint8_t);
+            else if (dtype == MA_U16) MA_BAND(uint16_t);
+            else MA_BAND(float);
+#undef MA_BAND
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipEventRecord(ev_k[(size_t)k * nband + b], ctx->stream);

@@ -42,10 +42,12 @@ def main(out_path):
     dist.barrier()
     # a download across the end of an owned row (the next row belongs to the other rank: not registered here) is staged
     # and still lands
-    if mine[0] + 1 < rows:
-        two = rng.random((2,) + shape).astype(np.float32)
-        ctx.asdevice(two).numpy(out=arr[mine[0]:mine[0] + 2])
-        ok = ok and np.array_equal(arr[mine[0]:mine[0] + 2], two)
+    for turn in range(ws):                             # one rank at a time: the spans of neighbouring ranks overlap
+        if turn == rank and mine[0] + 1 < rows:
+            two = rng.random((2,) + shape).astype(np.float32)
+            ctx.asdevice(two).numpy(out=arr[mine[0]:mine[0] + 2])
+            ok = ok and np.array_equal(arr[mine[0]:mine[0] + 2], two)
+        dist.barrier()
     res = [None] * ws
     dist.all_gather_object(res, {"rank": rank, "locked": locked, "direct_own": direct_own, "direct_other": direct_other,
                                  "direct_span": direct_span, "ok": bool(ok)})
