@@ -195,6 +195,19 @@ def roofline_entry(name, rec, iters, esz, steps=1, traffic_per_step=None, winsiz
                                      "ma_clock_probe, same run" if clock_ghz else "nominal"),
                     "clock_probe_ghz": round(clock_ghz, 3) if clock_ghz else None,
                     "flops_per_px": round(fpp, 1), "arithmetic": "fma" if fused else "mul+add (3 ops per tap pair)", "hbm": hbm})
+    if name == "warp":
+        # instruction bound, not bandwidth bound: VALU busy 0.90 at half the HBM rate (profiles/r05_sq_counters_cfg3.txt), 88
+        # VALU instructions per pixel measured (rocprofv3 SQ_INSTS_VALU, profiles/r06_notes.md: coordinate quantisation with
+        # cvtss2si semantics, weights from the 5-bit fractions, unfused blend, window-local indices, the by-products).  The
+        # bandwidth figures stay as the HBM view; the issue view prices those instructions against one per lane and cycle
+        ghz = clock_ghz or NOMINAL_GHZ
+        ipp = 88.0
+        rate = ipp * rec["px"] / sec / 1e12
+        peak_nom = VALU_LANES_PER_CLOCK * NOMINAL_GHZ * 1e9 / 1e12
+        out.update({"bound": "valu", "hbm": hbm,
+                    "valu": {"instructions_per_px": ipp, "source": "profiles/r06_notes.md (SQ_INSTS_VALU / pixels, cfg2)",
+                             "achieved": round(rate, 2), "peak": round(peak_nom, 2), "unit": "T lane-instructions/s",
+                             "frac": round(rate / peak_nom, 4), "clock_probe_ghz": round(ghz, 3)}})
     return out
 
 

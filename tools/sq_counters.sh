@@ -6,7 +6,9 @@
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 WL=${1:-cfg3}; TAG=${2:-tree}
-OUT=gpurun_out/sq_${WL}_${TAG}
+# a fresh directory per invocation: results of earlier invocations (gpurun merges them into the caller's gpurun_out/) must never
+# be summed into this one's (round 5's "library C" section was three runs added up: counts x 3, a 6 GHz clock)
+OUT=gpurun_out/sq_${WL}_${TAG}_$(date +%s)_$$
 rm -rf $OUT; mkdir -p $OUT
 CMD="python3 bench.py --workload $WL --steps 1 --warmup 1 --no-cpu-baseline --no-variants --no-companion"
 i=0
@@ -30,6 +32,7 @@ import csv, glob, sys, collections, re
 out = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 dur = collections.defaultdict(lambda: [0, 0.0])
+grbm_ms = collections.defaultdict(float)
 seen = set()
 for f in sorted(glob.glob(out + "/p*/*/*_counter_collection.csv")):
     pas = f.split("/")[-3]
@@ -48,6 +51,10 @@ for f in sorted(glob.glob(out + "/p*/*/*_counter_collection.csv")):
         if pas.endswith("p1") and tag not in seen and "End_Timestamp" in r:
             seen.add(tag)
             dur[key][0] += 1; dur[key][1] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6
+        # the clock comes from ONE pass: the GRBM pass's own cycle counts over its own launch durations
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and tag not in seen and "End_Timestamp" in r:
+            seen.add(tag)
+            grbm_ms[key] += (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e6
 for k in sorted(acc):
     d = acc[k]
     n, ms = dur[k]
@@ -59,8 +66,9 @@ for k in sorted(acc):
         simd_cycles = 1024 * g("GRBM_GUI_ACTIVE") / 8      # 256 CUs x 4 SIMDs x the kernel's cycles (GRBM is summed over 8 XCDs)
         if simd_cycles:
             print(f"   -- VALU-busy: SIMD cycles executing a VALU instruction   {g('SQ_ACTIVE_INST_VALU') * 4 / simd_cycles:.3f}   (ACTIVE_INST_* count quad-cycles summed over waves)")
-            print(f"   -- wave slots occupied (of 16 per CU)       {g('SQ_WAVE_CYCLES') * 4 / (4096 * g('GRBM_GUI_ACTIVE') / 8):.3f}")
-            print(f"   -- clock                                    {g('GRBM_GUI_ACTIVE') / 8 / (ms * 1e6) if ms else 0:.3f} GHz (cycles of the GRBM pass / duration of pass 1)")
+            print(f"   -- waves resident per SIMD (of 8 slots)     {g('SQ_WAVE_CYCLES') * 4 / simd_cycles:.2f}")
+            gm = grbm_ms.get(k, 0.0)
+            print(f"   -- clock                                    {g('GRBM_GUI_ACTIVE') / 8 / (gm * 1e6) if gm else 0:.3f} GHz (cycles and durations of the GRBM pass)")
         print(f"   -- wave cycles waiting on an instruction    {g('SQ_WAIT_INST_ANY') / max(g('SQ_WAVE_CYCLES'), 1):.3f} of wave cycles; waiting on anything {g('SQ_WAIT_ANY') / max(g('SQ_WAVE_CYCLES'), 1):.3f}")
         print(f"   -- VMEM instructions in flight per wave     {g('SQ_INST_LEVEL_VMEM') / max(g('SQ_WAVE_CYCLES'), 1):.3f}")
         print(f"   -- LDS bank-conflict share of LDS cycles    {g('SQ_LDS_BANK_CONFLICT') / max(g('SQ_LDS_IDX_ACTIVE'), 1):.4f}")
@@ -68,3 +76,4 @@ for k in sorted(acc):
     if g("TCC_HIT_sum") + g("TCC_MISS_sum"):
         print(f"   -- L2 hit rate                              {g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')):.3f}")
 PY
+cp $OUT/summary.txt gpurun_out/sq_${WL}_${TAG}.txt
