@@ -202,31 +202,51 @@ __global__ __launch_bounds__(RS_T) void rs_score_samples(const double* __restric
     if (threadIdx.x == 0) counts[s] = c;
 }
 
+// N sums at once (two barriers instead of two per sum); exact for integer-valued terms below 2^53, as above
+template <int T, int N>
+__device__ __forceinline__ void rs_block_sum_f64n(double (&v)[N], double* wsum /* [N][T / 64] */)
+{
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        for (int o = 32; o; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < N; k++) wsum[k * (T / 64) + (threadIdx.x >> 6)] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < T / 64; w++) t += wsum[k * (T / 64) + w];
+        v[k] = t;
+    }
+    __syncthreads();
+}
+
 // closed-form least squares over the points with mask[p] != 0 (sparse_cpu._fit_similarity); false: rank deficient
 __device__ bool rs_fit(const double* __restrict__ sx, const double* __restrict__ sy, const double* __restrict__ dx,
                        const double* __restrict__ dy, const unsigned char* __restrict__ mask, int n, int count, RsModel& m,
-                       double* wsum)
+                       double* wsum /* [7][RS_F / 64] */)
 {
     if (count < 2) return false;
     const double fn = (double)count;
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    double c4[4] = {0, 0, 0, 0};
     for (int p = threadIdx.x; p < n; p += RS_F)
-        if (mask[p]) { a0 += sx[p]; a1 += sy[p]; a2 += dx[p]; a3 += dy[p]; }
-    const double cx = floor(rs_block_sum_f64<RS_F>(a0, wsum) / fn), cy = floor(rs_block_sum_f64<RS_F>(a1, wsum) / fn);
-    const double cu = floor(rs_block_sum_f64<RS_F>(a2, wsum) / fn), cv = floor(rs_block_sum_f64<RS_F>(a3, wsum) / fn);
-    double p0 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, p5 = 0, p6 = 0;
+        if (mask[p]) { c4[0] += sx[p]; c4[1] += sy[p]; c4[2] += dx[p]; c4[3] += dy[p]; }
+    rs_block_sum_f64n<RS_F, 4>(c4, wsum);
+    const double cx = floor(c4[0] / fn), cy = floor(c4[1] / fn), cu = floor(c4[2] / fn), cv = floor(c4[3] / fn);
+    double q[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int p = threadIdx.x; p < n; p += RS_F)
         if (mask[p]) {
             const double x = sx[p] - cx, y = sy[p] - cy, u = dx[p] - cu, v = dy[p] - cv;
-            p0 += x; p1 += y; p2 += u; p3 += v;
-            p4 += x * x + y * y;
-            p5 += x * u + y * v;
-            p6 += x * v - y * u;
+            q[0] += x; q[1] += y; q[2] += u; q[3] += v;
+            q[4] += x * x + y * y;
+            q[5] += x * u + y * v;
+            q[6] += x * v - y * u;
         }
-    const double Sx = rs_block_sum_f64<RS_F>(p0, wsum), Sy = rs_block_sum_f64<RS_F>(p1, wsum);
-    const double Su = rs_block_sum_f64<RS_F>(p2, wsum), Sv = rs_block_sum_f64<RS_F>(p3, wsum);
-    const double Sxx = rs_block_sum_f64<RS_F>(p4, wsum), Sxu = rs_block_sum_f64<RS_F>(p5, wsum);
-    const double Sxv = rs_block_sum_f64<RS_F>(p6, wsum);
+    rs_block_sum_f64n<RS_F, 7>(q, wsum);
+    const double Sx = q[0], Sy = q[1], Su = q[2], Sv = q[3], Sxx = q[4], Sxu = q[5], Sxv = q[6];
     const double D = fn * Sxx - (Sx * Sx + Sy * Sy);
     if (!(D > 0.0)) return false;
     m.a = (fn * Sxu - (Sx * Su + Sy * Sv)) / D;
@@ -247,7 +267,7 @@ __global__ __launch_bounds__(RS_F) void rs_refine(const double* __restrict__ sx,
                                                   unsigned char* __restrict__ mask_a, unsigned char* __restrict__ mask_b,
                                                   double* __restrict__ out)
 {
-    __shared__ double wsum[RS_F / 64];
+    __shared__ double wsum[7 * (RS_F / 64)];
     __shared__ int isum[RS_F / 64];
     RsModel m;
     rs_two_point_model(sx, sy, dx, dy, pairs[2 * best], pairs[2 * best + 1], m);   // not degenerate: it was counted
@@ -275,8 +295,17 @@ __global__ __launch_bounds__(RS_F) void rs_refine(const double* __restrict__ sx,
             cnt += in;
             diff += in != best_mask[p] ? 1 : 0;
         }
-        cnt = rs_block_sum_int<RS_F>(cnt, isum);
-        diff = rs_block_sum_int<RS_F>(diff, isum);
+        {   // both counts in one reduction (n < 2^26: a count fits 26 bits; the sum of the packed words does not overflow 63)
+            long long both = ((long long)cnt << 32) | (long long)diff;
+            for (int o = 32; o; o >>= 1) both += __shfl_xor(both, o);
+            __shared__ long long lsum[RS_F / 64];
+            if ((threadIdx.x & 63) == 0) lsum[threadIdx.x >> 6] = both;
+            __syncthreads();
+            long long t = 0;
+            for (int w = 0; w < RS_F / 64; w++) t += lsum[w];
+            __syncthreads();
+            cnt = (int)(t >> 32); diff = (int)(t & 0xffffffffll);
+        }
         if (cnt < 2 || diff == 0) break;
         unsigned char* t = best_mask; best_mask = mask; mask = t;
         best_count = cnt;

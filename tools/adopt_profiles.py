@@ -43,5 +43,5 @@ if len(sys.argv) > 2:
                        "(MI355X_MICROARCH.md, DVFS); profiled passes run a few percent below unprofiled ones",
                "per_kernel": clk}, open(os.path.join(ROOT, "profiles", f"{tag}_kernel_clocks_cfg3.json"), "w"), indent=1)
 if len(sys.argv) > 3:
-    shutil.copy(sys.argv[3], os.path.join(ROOT, "profiles", f"{tag}_sq_counters_cfg2.txt"))
+    shutil.copy(sys.argv[3], os.path.join(ROOT, "profiles", f"{tag}_sq_counters_cfg3.txt"))
 print("adopted", tag, "for kernel sources", want)
