@@ -379,13 +379,16 @@ int ma_knn2_l2(ma_ctx* ctx, const float* query, int nq, const float* train, int 
                float* dist_out);
 
 /* The same search with the strategy chosen by the caller.  The RESULT is defined by the exact kernel in every mode.
- * MA_KNN_FILTERED (what MA_KNN_AUTO picks for big sets, dim <= 216): the train rows are first ranked by
- * |t|^2 - 2 q.t on the FP32 matrix cores (v_mfma_f32_32x32x2_f32, an exact fmaf chain), the four best of every split
- * of the train set are re-evaluated with the defining sum, and a rounding bound certifies that no other row can enter or
- * tie the pair; queries without a certificate (near-ties, duplicated descriptors) are served by the exact kernel.
- * Bit-identical to MA_KNN_EXACT by construction.  uncertified_host: NULL, or where to put the number of queries that
- * took the exact fallback (this makes the call synchronous). */
-enum ma_knn_mode { MA_KNN_AUTO = 0, MA_KNN_EXACT = 1, MA_KNN_FILTERED = 2 };
+ * MA_KNN_FILTERED (what MA_KNN_AUTO picks for big sets): the train rows are first ranked by |t|^2 - 2 q.t on the matrix
+ * cores, the four best of every split of the train set are re-evaluated with the defining sum, and a rounding bound
+ * certifies that no other row can enter or tie the pair; queries without a certificate (near-ties, duplicated
+ * descriptors) are served by the exact kernel.  Bit-identical to MA_KNN_EXACT by construction.  The ranking runs on the
+ * FP16 matrix cores with every operand scaled by a power of two and split into two float16 numbers (three
+ * v_mfma_f32_32x32x16_f16 per sixteen dimensions, dim <= 208; round 6) or, MA_KNN_FILTERED_F32 (dim <= 216; round 3), on
+ * the FP32 ones (v_mfma_f32_32x32x2_f32, an exact fmaf chain); the certificate's bound follows the ranking's error.
+ * uncertified_host: NULL, or where to put the number of queries that took the exact fallback (this makes the call
+ * synchronous). */
+enum ma_knn_mode { MA_KNN_AUTO = 0, MA_KNN_EXACT = 1, MA_KNN_FILTERED = 2, MA_KNN_FILTERED_F32 = 3 };
 int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const float* train, int nt, int dim, int* idx_out,
                   float* dist_out, int mode, int* uncertified_host);
 

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MICROALIGNER_HIP_LIB") or os.path.join(_HERE, "libmic
 MA_U8, MA_U16, MA_F32 = 0, 1, 2
 MA_OK, MA_EINVAL, MA_ENOMEM, MA_EHIP, MA_ENODEV = 0, -1, -2, -3, -4
 MA_FB_MULADD_FUSED = 1
-MA_KNN_AUTO, MA_KNN_EXACT, MA_KNN_FILTERED = 0, 1, 2   # enum ma_knn_mode
+MA_KNN_AUTO, MA_KNN_EXACT, MA_KNN_FILTERED, MA_KNN_FILTERED_F32 = 0, 1, 2, 3   # enum ma_knn_mode
 MA_DOG_FUSED_BLUR, MA_DOG_FUSED_SCALE, MA_DOG_REPORT_ASYNC = 1, 2, 4
 MA_FLOW_CELL_REPLICAS = 8
 MA_OPT_COMPANION_STREAM, MA_OPT_WORKSPACE_LIMIT, MA_OPT_WARP_BAND_BYTES = 1, 2, 3      # enum ma_option

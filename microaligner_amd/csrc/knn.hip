@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <string>
 
 namespace {
 
@@ -348,11 +350,13 @@ __global__ __launch_bounds__(KM_THREADS) void km_shortlist(const float* __restri
 
 // One thread per (query, candidate): the defining sum; then per query the two smallest by (distance, index) and the
 // certificate.  sc = candidates per query rounded up to a power of two (<= 32), 256 / sc queries per block.
+// half16: the shortlist came from kh_shortlist (split-float16 products on the FP16 matrix cores); its ranking values carry a
+// larger error than the FP32 chain's (bound below); amax: bit patterns of max |q|, max |t| over all elements (kh_absmax).
 __global__ __launch_bounds__(256) void km_refine(const float* __restrict__ q, const float* __restrict__ t, int nq, int dim,
                                                  int nsplit, int sc, const int* __restrict__ cand_idx,
                                                  const float* __restrict__ cand_a4, const unsigned* __restrict__ tmax_bits,
                                                  int* __restrict__ idx, float* __restrict__ dist, int* __restrict__ qlist,
-                                                 int* __restrict__ qcount)
+                                                 int* __restrict__ qcount, int half16, const unsigned* __restrict__ amax)
 {
     __shared__ float sd[256];
     __shared__ int si[256];
@@ -407,14 +411,217 @@ __global__ __launch_bounds__(256) void km_refine(const float* __restrict__ q, co
     for (int s = 0; s < nsplit; s++) a4 = fminf(a4, cand_a4[(size_t)s * nq + qi]);
     const double u = 5.9604644775390625e-8, g = (dim + 4) * u * 1.01, dl = (dim + 3) * u * 1.01;
     const double tm = (double)__uint_as_float(*tmax_bits) * (1.0 + 2.0 * g), qq = (double)qn;
-    const double err = g * (tm + 2.0 * sqrt(qq * (1.0 + 2.0 * g) * tm)) * 1.001;
+    double err = g * (tm + 2.0 * sqrt(qq * (1.0 + 2.0 * g) * tm)) * 1.001;
+    if (half16) {
+        // a_j = n2_j - 2 D with n2_j the FP32 chain of km_norms (error <= g |t_j|^2) and D the sum of the three split products
+        // xh yh + xh yl + xl yh of the scaled operands on v_mfma_f32_32x32x16_f16.  With x = xh + xl + e:
+        //   representation  |e| <= 2^-22 |x| (two roundings to 11 bits) where the low part is a normal float16, else the low
+        //                   part's magnitude <= 2^-14 in scaled units (a denormal the unit may flush) = e_abs per element;
+        //   dropped term    |xl yl| <= 2^-22 |x||y|;
+        //   accumulation    products of two 11-bit numbers are exact in FP32; the instruction aligns its sixteen products and
+        //                   the accumulator to the largest of them and drops what falls below the last place (measured,
+        //                   tools/ubench_mfma_f16_err.hip: up to 0.89 K u sum|terms| on operands spanning nine decades; plain
+        //                   truncation to 24 bits would allow 2 u per term): every addition is charged FOUR units u = 2^-24 of
+        //                   the running sum of magnitudes; float16 DENORMAL operands are flushed (same measurement): e_abs.
+        // |D - q.t| <= eps |q||t| + e_abs sqrt(dim) (|q| + |t|),  eps = 4 * 2^-22 + 4 * (3 dimp + 2) * 2^-24, all times 1.01.
+        const int dimp = (dim + 15) & ~15;
+        const double eps = (4.0 * 2.384185791015625e-7 + 4.0 * (3.0 * dimp + 2.0) * u) * 1.01;
+        const double aq = (double)__uint_as_float(amax[0]), at = (double)__uint_as_float(amax[1]);
+        // scaled maxima lie in [2^12, 2^13): the scale is at least 2^12 / max, a scaled 2^-14 is at most 2^-26 max
+        const double eabs = 1.4901161193847656e-8 * (aq > at ? aq : at) * 1.01;
+        const double nq2 = sqrt(qq * (1.0 + 2.0 * g)), nt2 = sqrt(tm);
+        err = (g * tm + 2.0 * (eps * nq2 * nt2 + eabs * sqrt((double)dim) * (nq2 + nt2)) + u * (tm + 2.0 * nq2 * nt2)) * 1.001;
+    }
     const double lower = ((double)a4 - err + qq * (1.0 - 2.0 * g)) * (1.0 - dl);
-    const bool certified = (double)d1 < lower;      // strictly: a tie would have to be broken by index
+    // The bounds are RELATIVE ones: they hold while squared norms and products stay in float32's normal range.  Sets whose
+    // magnitudes sit near its ends (|x| ~ 1e-20: squared norms are denormals, the split operands' unscaling underflows) get
+    // no certificate at all -- every query then takes the exact pass.
+    bool in_range = tm > 1e-30 && tm < 1e30;
+    if (half16) {
+        const int eq = (int)((amax[0] >> 23) & 255u) - 127, et = (int)((amax[1] >> 23) & 255u) - 127;
+        in_range = in_range && amax[0] != 0u && amax[1] != 0u && eq > -40 && eq < 40 && et > -40 && et < 40;
+    }
+    const bool certified = in_range && (double)d1 < lower;      // strictly: a tie would have to be broken by index
     idx[(size_t)qi * 2] = i0;
     idx[(size_t)qi * 2 + 1] = i1;
     dist[(size_t)qi * 2] = d0;
     dist[(size_t)qi * 2 + 1] = d1;
     if (!certified) qlist[atomicAdd(qcount, 1)] = qi;
+}
+
+// ---- split-float16 shortlist (round 6) ---------------------------------------------------------------------------------
+// The same ranking a_j = |t_j|^2 - 2 q.t_j with the dot product on the FP16 matrix cores (v_mfma_f32_32x32x16_f16: sixteen
+// times the FP32 rate).  Every operand is scaled by a power of two (its set's largest magnitude goes to [2^12, 2^13)) and cut
+// into two float16 numbers, x = xh + xl (22 bits of the 24); q.t ~ sum qh th + qh tl + ql th, three matrix instructions per
+// sixteen dimensions, accumulated in FP32.  What that costs in accuracy is in km_refine's bound; the certificate decides, as
+// before, which queries need the exact pass -- the RESULT stays that of knn2_kernel, bit for bit.
+typedef _Float16 kh_h8 __attribute__((ext_vector_type(8)));
+constexpr int KH_NQ = 128, KH_NT = 128, KH_KC = 32, KH_TP = KH_KC + 8, KH_THREADS = 512;
+constexpr int KH_MAX_DIM = 208;       // Q tile 2 x 128 x (208 + 8) halves + two T chunks + norms within 160 KB
+
+__global__ __launch_bounds__(256) void kh_absmax(const float* __restrict__ x, size_t n, unsigned* __restrict__ out_bits)
+{
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));       // non-negative floats order like their bits
+}
+
+// exponent e of the scale 2^e that takes a set whose largest magnitude has these bits into [2^12, 2^13)
+__device__ __forceinline__ int kh_scale_exp(unsigned maxbits)
+{
+    const int ex = (int)((maxbits >> 23) & 255u) - 127;
+    if (maxbits == 0u || ex <= -40 || ex >= 40) return 0;       // empty / tiny / huge: unscaled (km_refine certifies nothing then)
+    return 12 - ex;
+}
+
+__global__ __launch_bounds__(256) void kh_split(const float* __restrict__ x, int n, int dim, int dimp,
+                                                const unsigned* __restrict__ maxbits, _Float16* __restrict__ xh,
+                                                _Float16* __restrict__ xl)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)n * dimp) return;
+    const int row = (int)(e / dimp), k = (int)(e - (size_t)row * dimp);
+    float v = k < dim ? ldexpf(x[(size_t)row * dim + k], kh_scale_exp(*maxbits)) : 0.f;
+    const _Float16 h = (_Float16)v;
+    xh[e] = h;
+    xl[e] = (_Float16)(v - (float)h);
+}
+
+// grid (query tiles, splits); 8 waves as in km_shortlist: wave w ranks the train rows 32 (w & 3) .. + 32 of every 128-row tile
+// against the queries 64 (w >> 2) .. + 64 (two 32 x 32 accumulator tiles).  Lane half h holds the dimensions 16 s + 8 h .. + 8
+// of step s for both operands (one 16-byte LDS read each).
+__global__ __launch_bounds__(KH_THREADS) void kh_shortlist(const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,
+                                                           const _Float16* __restrict__ th, const _Float16* __restrict__ tl,
+                                                           const float* __restrict__ nt2, int nq, int nt, int dimp,
+                                                           int tiles_per_split, const unsigned* __restrict__ amax,
+                                                           int* __restrict__ cand_idx, float* __restrict__ cand_a4)
+{
+    extern __shared__ _Float16 hl[];
+    const int qp = dimp + 8;
+    _Float16* Qh = hl;                                 // [KH_NQ][qp]
+    _Float16* Ql = Qh + KH_NQ * qp;
+    _Float16* Th = Ql + KH_NQ * qp;                    // [2][KH_NT][KH_TP]
+    _Float16* Tl = Th + 2 * KH_NT * KH_TP;
+    float* Ns = reinterpret_cast<float*>(Tl + 2 * KH_NT * KH_TP);   // [2][KH_NT]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 3, wn = w >> 2, lr = lane & 31, lh = lane >> 5;
+    const int q0 = blockIdx.x * KH_NQ, split = blockIdx.y;
+    const int tile0 = split * tiles_per_split, ntiles_all = (nt + KH_NT - 1) / KH_NT;
+    const int ntiles = min(tiles_per_split, ntiles_all - tile0);
+    const int cpt = (dimp + KH_KC - 1) / KH_KC;        // chunks per train tile
+    const int nchunks = ntiles * cpt;
+    // -2 / (scale of q x scale of t): exact (a power of two)
+    const float unscale = ldexpf(-2.f, -(kh_scale_exp(amax[0]) + kh_scale_exp(amax[1])));
+
+    {
+        const int segs = dimp / 8;                     // 16-byte pieces per row
+        for (int e = tid; e < KH_NQ * segs; e += KH_THREADS) {
+            const int row = e / segs, sg = e - row * segs;
+            uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
+            if (q0 + row < nq) {
+                vh = reinterpret_cast<const uint4*>(qh + (size_t)(q0 + row) * dimp)[sg];
+                vl = reinterpret_cast<const uint4*>(ql + (size_t)(q0 + row) * dimp)[sg];
+            }
+            *reinterpret_cast<uint4*>(Qh + row * qp + 8 * sg) = vh;
+            *reinterpret_cast<uint4*>(Ql + row * qp + 8 * sg) = vl;
+        }
+    }
+
+    uint4 sh = make_uint4(0, 0, 0, 0), sl = sh;
+    float nstage = 0.f;
+    const int srow = tid >> 2, sseg = tid & 3;         // this thread's piece of a staged chunk: row, 8-half segment
+    auto fetch = [&](int c) {
+        const int tile = tile0 + c / cpt, k0 = (c % cpt) * KH_KC, t0 = tile * KH_NT;
+        sh = make_uint4(0, 0, 0, 0); sl = sh;
+        if (t0 + srow < nt && k0 + 8 * sseg < dimp) {
+            sh = *reinterpret_cast<const uint4*>(th + (size_t)(t0 + srow) * dimp + k0 + 8 * sseg);
+            sl = *reinterpret_cast<const uint4*>(tl + (size_t)(t0 + srow) * dimp + k0 + 8 * sseg);
+        }
+        if (c % cpt == 0 && tid < KH_NT) nstage = t0 + tid < nt ? nt2[t0 + tid] : INFINITY;   // rows past the end rank last
+    };
+    auto commit = [&](int c) {
+        *reinterpret_cast<uint4*>(Th + ((c & 1) * KH_NT + srow) * KH_TP + 8 * sseg) = sh;
+        *reinterpret_cast<uint4*>(Tl + ((c & 1) * KH_NT + srow) * KH_TP + 8 * sseg) = sl;
+        if (c % cpt == 0 && tid < KH_NT) Ns[((c / cpt) & 1) * KH_NT + tid] = nstage;
+    };
+
+    Top4 best[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int e = 0; e < KM_K; e++) { best[n].d[e] = INFINITY; best[n].i[e] = 0x7fffffff; }
+
+    if (nchunks > 0) { fetch(0); commit(0); }
+    __syncthreads();
+    km_f16 acc[2];
+    for (int c = 0; c < nchunks; c++) {
+        const int kc = c % cpt, k0 = kc * KH_KC;
+        if (c + 1 < nchunks) fetch(c + 1);
+        if (kc == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        }
+        const int toff = ((c & 1) * KH_NT + 32 * wm + lr) * KH_TP + 8 * lh;
+        const int qoff = (64 * wn + lr) * qp + k0 + 8 * lh;
+        const int steps = min(KH_KC, dimp - k0) / 16;
+        for (int st = 0; st < steps; st++) {
+            const kh_h8 ah = *reinterpret_cast<const kh_h8*>(Th + toff + 16 * st);
+            const kh_h8 al = *reinterpret_cast<const kh_h8*>(Tl + toff + 16 * st);
+            const kh_h8 b0h = *reinterpret_cast<const kh_h8*>(Qh + qoff + 16 * st);
+            const kh_h8 b0l = *reinterpret_cast<const kh_h8*>(Ql + qoff + 16 * st);
+            const kh_h8 b1h = *reinterpret_cast<const kh_h8*>(Qh + qoff + 32 * qp + 16 * st);
+            const kh_h8 b1l = *reinterpret_cast<const kh_h8*>(Ql + qoff + 32 * qp + 16 * st);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1h, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b0l, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b1l, acc[1], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b0h, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b1h, acc[1], 0, 0, 0);
+        }
+        if (kc == cpt - 1) {
+            // a_j = |t_j|^2 - 2 q.t_j for the 16 train rows this lane holds of either query
+            const int tile = c / cpt, t0 = (tile0 + tile) * KH_NT + 32 * wm + 4 * lh;
+            const float* nrm = Ns + (tile & 1) * KH_NT + 32 * wm + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                const float n2 = nrm[row];
+#pragma unroll
+                for (int n = 0; n < 2; n++) {
+                    const float v = __builtin_fmaf(unscale, acc[n][r], n2);
+                    if (v < best[n].d[KM_K - 1]) top4_push(best[n], v, t0 + row);
+                }
+            }
+        }
+        if (c + 1 < nchunks) commit(c + 1);
+        __syncthreads();
+    }
+
+    // the eight partial lists of every query (four row groups x two lane halves) -> its four smallest
+    float* cd = reinterpret_cast<float*>(Th);                  // [KH_NQ][8][KM_K]: 16 KB of the T buffers' 40
+    int* ci = reinterpret_cast<int*>(cd + KH_NQ * 8 * KM_K);
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+        for (int e = 0; e < KM_K; e++) {
+            const int o = ((64 * wn + 32 * n + lr) * 8 + wm * 2 + lh) * KM_K + e;
+            cd[o] = best[n].d[e];
+            ci[o] = best[n].i[e];
+        }
+    __syncthreads();
+    if (tid < KH_NQ && q0 + tid < nq) {
+        Top4 m;
+#pragma unroll
+        for (int e = 0; e < KM_K; e++) { m.d[e] = INFINITY; m.i[e] = 0x7fffffff; }
+        for (int e = 0; e < 8 * KM_K; e++) {
+            const float v = cd[tid * 8 * KM_K + e];
+            if (v < m.d[KM_K - 1]) top4_push(m, v, ci[tid * 8 * KM_K + e]);
+        }
+        const size_t o = (size_t)split * nq + q0 + tid;
+#pragma unroll
+        for (int e = 0; e < KM_K; e++) cand_idx[o * KM_K + e] = m.i[e];
+        cand_a4[o] = m.d[KM_K - 1];     // every row of the split that is not listed ranks at or above this
+    }
 }
 
 } // namespace
@@ -448,13 +655,18 @@ extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const floa
     MA_REQUIRE(ctx && query && train && idx_out && dist_out, "NULL argument");
     MA_REQUIRE(nq >= 1 && nt >= 2, "need at least one query and two train descriptors");
     MA_REQUIRE(dim >= 4 && dim % 4 == 0, "the descriptor length must be a multiple of 4 (pad with zeros)");
-    MA_REQUIRE(mode == MA_KNN_AUTO || mode == MA_KNN_EXACT || mode == MA_KNN_FILTERED, "unknown search mode");
-    MA_REQUIRE(mode != MA_KNN_FILTERED || dim <= KM_MAX_DIM, "the filtered search holds descriptors of up to 216 floats");
+    MA_REQUIRE(mode == MA_KNN_AUTO || mode == MA_KNN_EXACT || mode == MA_KNN_FILTERED || mode == MA_KNN_FILTERED_F32,
+               "unknown search mode");
+    MA_REQUIRE((mode != MA_KNN_FILTERED && mode != MA_KNN_FILTERED_F32) || dim <= KM_MAX_DIM,
+               "the filtered search holds descriptors of up to 216 floats");
     MA_HIP(hipSetDevice(ctx->device));
     if (uncertified_host) *uncertified_host = 0;
     // the shortlist pays once the distance matrix is big; below that the exact kernel is already launch-bound
-    const bool filtered = mode == MA_KNN_FILTERED ||
+    const bool filtered = mode == MA_KNN_FILTERED || mode == MA_KNN_FILTERED_F32 ||
                           (mode == MA_KNN_AUTO && dim <= KM_MAX_DIM && nt >= 4 * KM_NT && (double)nq * nt >= 4e6);
+    // the shortlist on the FP16 matrix cores (split-float16 operands) unless the caller asks for round 3's FP32 one
+    static const bool env_f32 = [] { const char* e = getenv("MICROALIGNER_KNN_SHORTLIST"); return e && std::string(e) == "f32"; }();
+    const bool half16 = filtered && mode != MA_KNN_FILTERED_F32 && !env_f32 && dim <= KH_MAX_DIM;
     if (!filtered) return knn2_exact(ctx, query, nq, train, nt, dim, idx_out, dist_out, nullptr, nullptr, 1, nullptr);
 
     // splits of the train set: enough blocks to fill 256 CUs in whole rounds, every split at least one 128-row tile
@@ -474,7 +686,9 @@ extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const floa
     const size_t b_nt2 = ma_align_up((size_t)nt * 4, 256), b_ci = ma_align_up((size_t)nsplit * nq * KM_K * 4, 256),
                  b_a4 = ma_align_up((size_t)nsplit * nq * 4, 256), b_ql = ma_align_up((size_t)nq * 4, 256),
                  b_part = fsplit > 1 ? (size_t)fsplit * nq * sizeof(float4) : 0;
-    char* ws = static_cast<char*>(ma_pool_alloc(ctx, b_nt2 + b_ci + b_a4 + b_ql + 256 + b_part));
+    const int dimh = (dim + 15) & ~15;                           // split operands: rows of dimh float16
+    const size_t b_qs = half16 ? ma_align_up((size_t)nq * dimh * 2, 256) : 0, b_ts = half16 ? ma_align_up((size_t)nt * dimh * 2, 256) : 0;
+    char* ws = static_cast<char*>(ma_pool_alloc(ctx, b_nt2 + b_ci + b_a4 + b_ql + 256 + b_part + 2 * b_qs + 2 * b_ts));
     if (!ws) return MA_ENOMEM;
     float* nt2 = reinterpret_cast<float*>(ws);
     int* cand_idx = reinterpret_cast<int*>(ws + b_nt2);
@@ -483,10 +697,33 @@ extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const floa
     unsigned* tmax = reinterpret_cast<unsigned*>(ws + b_nt2 + b_ci + b_a4 + b_ql);
     int* qcount = reinterpret_cast<int*>(tmax + 1);
     float4* part = b_part ? reinterpret_cast<float4*>(ws + b_nt2 + b_ci + b_a4 + b_ql + 256) : nullptr;
+    unsigned* amax = tmax + 2;                                   // max |q|, max |t| (bit patterns)
+    char* split0 = ws + b_nt2 + b_ci + b_a4 + b_ql + 256 + b_part;
+    _Float16 *qh = (_Float16*)split0, *ql = (_Float16*)(split0 + b_qs), *th = (_Float16*)(split0 + 2 * b_qs),
+             *tl = (_Float16*)(split0 + 2 * b_qs + b_ts);
     int rc = MA_OK;
     do {
-        if (hipMemsetAsync(tmax, 0, 8, ctx->stream) != hipSuccess) { rc = MA_EHIP; break; }
-        {
+        if (hipMemsetAsync(tmax, 0, 16, ctx->stream) != hipSuccess) { rc = MA_EHIP; break; }
+        if (half16) {
+            MaProfScope ps(ctx, MA_K_OTHER, (double)nq);
+            hipLaunchKernelGGL(km_norms, dim3((nt + 255) / 256), dim3(256), 0, ctx->stream, train, nt, dim, nt2, tmax);
+            const size_t eq = (size_t)nq * dim, et = (size_t)nt * dim;
+            hipLaunchKernelGGL(kh_absmax, dim3((unsigned)std::min<size_t>(1024, (eq + 255) / 256)), dim3(256), 0, ctx->stream, query, eq, amax);
+            hipLaunchKernelGGL(kh_absmax, dim3((unsigned)std::min<size_t>(1024, (et + 255) / 256)), dim3(256), 0, ctx->stream, train, et, amax + 1);
+            hipLaunchKernelGGL(kh_split, dim3((unsigned)(((size_t)nq * dimh + 255) / 256)), dim3(256), 0, ctx->stream, query, nq, dim, dimh,
+                               (const unsigned*)amax, qh, ql);
+            hipLaunchKernelGGL(kh_split, dim3((unsigned)(((size_t)nt * dimh + 255) / 256)), dim3(256), 0, ctx->stream, train, nt, dim, dimh,
+                               (const unsigned*)(amax + 1), th, tl);
+            const size_t lds = (size_t)(2 * KH_NQ * (dimh + 8) + 4 * KH_NT * KH_TP) * sizeof(_Float16) + 2 * KH_NT * sizeof(float);
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kh_shortlist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) { rc = MA_EHIP; break; }
+            hipLaunchKernelGGL(kh_shortlist, dim3(nqt, nsplit), dim3(KH_THREADS), lds, ctx->stream, (const _Float16*)qh,
+                               (const _Float16*)ql, (const _Float16*)th, (const _Float16*)tl, (const float*)nt2, nq, nt, dimh,
+                               tiles_per_split, (const unsigned*)amax, cand_idx, cand_a4);
+            hipLaunchKernelGGL(km_refine, dim3((nq + 256 / sc - 1) / (256 / sc)), dim3(256), 0, ctx->stream, query, train, nq,
+                               dim, nsplit, sc, cand_idx, cand_a4, tmax, idx_out, dist_out, qlist, qcount, 1, (const unsigned*)amax);
+            if (hipGetLastError() != hipSuccess) { rc = MA_EHIP; break; }
+        } else {
             MaProfScope ps(ctx, MA_K_OTHER, (double)nq);
             hipLaunchKernelGGL(km_norms, dim3((nt + 255) / 256), dim3(256), 0, ctx->stream, train, nt, dim, nt2, tmax);
             const int dimp = (dim + 7) & ~7;
@@ -496,7 +733,7 @@ extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const floa
             hipLaunchKernelGGL(km_shortlist, dim3(nqt, nsplit), dim3(KM_THREADS), lds, ctx->stream, query, train, nt2, nq, nt,
                                dim, tiles_per_split, cand_idx, cand_a4);
             hipLaunchKernelGGL(km_refine, dim3((nq + 256 / sc - 1) / (256 / sc)), dim3(256), 0, ctx->stream, query, train, nq,
-                               dim, nsplit, sc, cand_idx, cand_a4, tmax, idx_out, dist_out, qlist, qcount);
+                               dim, nsplit, sc, cand_idx, cand_a4, tmax, idx_out, dist_out, qlist, qcount, 0, (const unsigned*)amax);
             if (hipGetLastError() != hipSuccess) { rc = MA_EHIP; break; }
         }
         rc = knn2_exact(ctx, query, nq, train, nt, dim, idx_out, dist_out, qlist, qcount, fsplit, part);

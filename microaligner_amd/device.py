@@ -775,13 +775,13 @@ class Context:
         """Exact 2-NN (L2) of every row of `query` among the rows of `train`: (idx (n, 2) int64, dist (n, 2) float32)
         on the host, like feature_reg.sparse_cpu.knn2.  Either side may be a host array or a DeviceArray (descriptors
         that ma_daisy_describe left on the device are searched where they are).
-        mode: "auto" | "exact" | "filtered" (ma_knn2_l2_ex: matrix-core shortlist + exact re-evaluation + certificate;
-        the same result bit for bit); stats: a dict that receives {"uncertified": queries served by the exact fallback}.
+        mode: "auto" | "exact" | "filtered" | "filtered_f32" (ma_knn2_l2_ex: matrix-core shortlist -- split-float16 or FP32 --
+        + exact re-evaluation + certificate; the same result bit for bit); stats: a dict that receives {"uncertified": queries served by the exact fallback}.
         on_device: leave the results where they are -- (idx (n, 2) int32 bits, SQUARED dist (n, 2) float32) device buffers, what
         match_similarity takes."""
-        modes = {"auto": L.MA_KNN_AUTO, "exact": L.MA_KNN_EXACT, "filtered": L.MA_KNN_FILTERED}
+        modes = {"auto": L.MA_KNN_AUTO, "exact": L.MA_KNN_EXACT, "filtered": L.MA_KNN_FILTERED, "filtered_f32": L.MA_KNN_FILTERED_F32}
         if mode not in modes:
-            raise ValueError(f"unknown search mode {mode!r}: auto, exact or filtered")
+            raise ValueError(f"unknown search mode {mode!r}: auto, exact, filtered or filtered_f32")
         def prep(a):
             if isinstance(a, DeviceArray):
                 if a.ndim != 2 or a.dtype != np.float32 or a.shape[1] % 4:

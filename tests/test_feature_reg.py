@@ -337,21 +337,42 @@ def _knn_case(kind, nq, nt, dim, seed):
         rows = np.repeat(base, nt, 0)
         t = np.where(rng.random((nt, dim)) < 0.5, rows, np.nextafter(rows, np.float32(2), dtype=np.float32))
         return rng.random((nq, dim)).astype(np.float32), t
+    if kind == "wide_range":       # magnitudes over nine decades within every row: the split-float16 operands lose the small ones
+        mag = np.exp(rng.uniform(np.log(1e-6), np.log(1e3), (nt, dim)))
+        t = (rng.standard_normal((nt, dim)) * mag).astype(np.float32)
+        q = (t[rng.integers(0, nt, nq)] * (1 + 1e-3 * rng.standard_normal((nq, dim)))).astype(np.float32)
+        return q, t
+    if kind == "tiny":             # everything around 1e-20: only the power-of-two scaling keeps it out of the float16 underflow
+        return (rng.random((nq, dim)) * 1e-20).astype(np.float32), (rng.random((nt, dim)) * 1e-20).astype(np.float32)
+    if kind == "outlier":          # one huge element sets the scale of the whole set
+        q, t = rng.random((nq, dim)).astype(np.float32), rng.random((nt, dim)).astype(np.float32)
+        t[nt // 2, 3] = 3e4
+        q[0, 5] = 1e5
+        return q, t
+    if kind == "clusters":         # tight clusters: many train rows within 1e-4 relative of each query's neighbours
+        centres = rng.random((40, dim)).astype(np.float32)
+        t = (centres[rng.integers(0, 40, nt)] + 1e-4 * rng.standard_normal((nt, dim))).astype(np.float32)
+        q = (centres[rng.integers(0, 40, nq)] + 1e-4 * rng.standard_normal((nq, dim))).astype(np.float32)
+        return q, t
     raise KeyError(kind)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["filtered", "filtered_f32"])
 @pytest.mark.parametrize("kind,nq,nt,dim", [
     ("uniform", 1000, 3000, 200), ("uniform", 129, 1000, 200), ("uniform", 1, 2, 200), ("uniform", 300, 5, 8),
     ("uniform", 257, 131, 216), ("uniform", 64, 700, 12), ("histograms", 2500, 4100, 200), ("duplicates", 500, 1500, 200),
-    ("near_ties", 200, 900, 200), ("uniform", 6000, 9000, 200)])
-def test_filtered_knn2_equals_the_exact_search(ctx, kind, nq, nt, dim):
-    """ma_knn2_l2_ex: the matrix-core shortlist + exact re-evaluation + certificate returns, bit for bit, what the exact
-    kernel returns -- on easy data through the certificate, on ties and duplicates through the exact fallback."""
+    ("near_ties", 200, 900, 200), ("uniform", 6000, 9000, 200), ("wide_range", 700, 2100, 200), ("tiny", 400, 1300, 200),
+    ("outlier", 500, 1500, 200), ("clusters", 900, 2600, 200), ("histograms", 333, 1111, 44), ("uniform", 200, 600, 208)])
+def test_filtered_knn2_equals_the_exact_search(ctx, kind, nq, nt, dim, mode):
+    """ma_knn2_l2_ex: the matrix-core shortlist (split-float16 operands on the FP16 cores, or round 3's FP32 one) + exact
+    re-evaluation + certificate returns, bit for bit, what the exact kernel returns -- on easy data through the certificate, on
+    ties, duplicates and data the split operands cannot resolve (nine decades of magnitude, tight clusters) through the exact
+    fallback."""
     q, t = _knn_case(kind, nq, nt, dim, seed=nq + nt)
     dq, dt = ctx.asdevice(q), ctx.asdevice(t)
     stats = {}
-    fi, fd = ctx.knn2(dq, dt, mode="filtered", stats=stats)
+    fi, fd = ctx.knn2(dq, dt, mode=mode, stats=stats)
     ei, ed = ctx.knn2(dq, dt, mode="exact")
     assert np.array_equal(fi, ei) and np.array_equal(fd, ed), (kind, stats)
     if nq * nt <= 3000 * 5000:
