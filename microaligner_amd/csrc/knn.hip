@@ -37,10 +37,12 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
 {
     extern __shared__ float lds[];
     const int cap = nq;                      // list positions the partial results are laid out for
-    if (qlist) {
-        nq = *qcount;
-        if ((int)blockIdx.x * KN_TQ >= nq) return;
-    }
+    if (qlist) nq = *qcount;
+    // a list is served by a FEW blocks per train range, each walking the list in steps of the grid (the grid cannot be sized
+    // for a count that lives on the device: one block per 64 of ALL queries made 22 000 blocks of which six had work, and
+    // their launch cost more than the work -- 150 us per match)
+  for (int qtile = blockIdx.x; qtile * KN_TQ < nq; qtile += gridDim.x) {
+    __syncthreads();                         // the previous tile's merge has left the LDS buffer
     // gridDim.y > 1: this block serves the train rows [tbeg, tend) only and leaves its pair per query in `part`
     // (knn2_merge_parts folds them): a handful of queries then occupies the whole chip instead of one CU
     const int tbeg = gridDim.y > 1 ? (int)blockIdx.y * split_rows : 0;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
     float* Qs = lds;                         // [KN_TQ][qp]
     float* Ts = lds + KN_TQ * qp;            // [KN_TT][KN_TP]
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int q0 = blockIdx.x * KN_TQ;
+    const int q0 = qtile * KN_TQ;
     for (int e = tid; e < KN_TQ * (dim / 4); e += 256) {
         const int row = e / (dim / 4), k4 = e - row * (dim / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -129,14 +131,15 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
         }
         if (gridDim.y > 1) {
             part[(size_t)blockIdx.y * cap + q0 + tid] = make_float4(d0, d1, __int_as_float(i0), __int_as_float(i1));
-            return;
+        } else {
+            const size_t o = (size_t)(qlist ? qlist[q0 + tid] : q0 + tid) * 2;
+            idx[o] = i0;
+            idx[o + 1] = i1;
+            dist[o] = d0;      // squared; the caller takes the root
+            dist[o + 1] = d1;
         }
-        const size_t o = (size_t)(qlist ? qlist[q0 + tid] : q0 + tid) * 2;
-        idx[o] = i0;
-        idx[o + 1] = i1;
-        dist[o] = d0;      // squared; the caller takes the root
-        dist[o + 1] = d1;
     }
+  }
 }
 
 // the pairs the train splits of knn2_kernel left for list position p -> the pair of query qlist[p]
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(KM_THREADS) void km_shortlist(const float* __restri
 // One thread per (query, candidate): the defining sum; then per query the two smallest by (distance, index) and the
 // certificate.  sc = candidates per query rounded up to a power of two (<= 32), 256 / sc queries per block.
 // half16: the shortlist came from kh_shortlist (split-float16 products on the FP16 matrix cores); its ranking values carry a
-// larger error than the FP32 chain's (bound below); amax: bit patterns of max |q|, max |t| over all elements (kh_absmax).
+// larger error than the FP32 chain's (bound below); amax: bit patterns of the largest squared norm of the queries and of the
+// train rows (km_norms), which set the operands' scales.
 __global__ __launch_bounds__(256) void km_refine(const float* __restrict__ q, const float* __restrict__ t, int nq, int dim,
                                                  int nsplit, int sc, const int* __restrict__ cand_idx,
                                                  const float* __restrict__ cand_a4, const unsigned* __restrict__ tmax_bits,
@@ -426,9 +430,9 @@ __global__ __launch_bounds__(256) void km_refine(const float* __restrict__ q, co
         // |D - q.t| <= eps |q||t| + e_abs sqrt(dim) (|q| + |t|),  eps = 4 * 2^-22 + 4 * (3 dimp + 2) * 2^-24, all times 1.01.
         const int dimp = (dim + 15) & ~15;
         const double eps = (4.0 * 2.384185791015625e-7 + 4.0 * (3.0 * dimp + 2.0) * u) * 1.01;
-        const double aq = (double)__uint_as_float(amax[0]), at = (double)__uint_as_float(amax[1]);
-        // scaled maxima lie in [2^12, 2^13): the scale is at least 2^12 / max, a scaled 2^-14 is at most 2^-26 max
-        const double eabs = 1.4901161193847656e-8 * (aq > at ? aq : at) * 1.01;
+        // the scale of a set is at least 2^11.5 / (its largest norm): a scaled 2^-14 is at most 2^-25.5 of that norm
+        const double aq = sqrt((double)__uint_as_float(amax[0])), at = sqrt((double)__uint_as_float(amax[1]));
+        const double eabs = 2.1073424255447017e-8 * (aq > at ? aq : at) * 1.01;
         const double nq2 = sqrt(qq * (1.0 + 2.0 * g)), nt2 = sqrt(tm);
         err = (g * tm + 2.0 * (eps * nq2 * nt2 + eabs * sqrt((double)dim) * (nq2 + nt2)) + u * (tm + 2.0 * nq2 * nt2)) * 1.001;
     }
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(256) void km_refine(const float* __restrict__ q, co
     bool in_range = tm > 1e-30 && tm < 1e30;
     if (half16) {
         const int eq = (int)((amax[0] >> 23) & 255u) - 127, et = (int)((amax[1] >> 23) & 255u) - 127;
-        in_range = in_range && amax[0] != 0u && amax[1] != 0u && eq > -40 && eq < 40 && et > -40 && et < 40;
+        in_range = in_range && amax[0] != 0u && amax[1] != 0u && eq > -80 && eq < 80 && et > -80 && et < 80;
     }
     const bool certified = in_range && (double)d1 < lower;      // strictly: a tie would have to be broken by index
     idx[(size_t)qi * 2] = i0;
@@ -459,20 +463,14 @@ typedef _Float16 kh_h8 __attribute__((ext_vector_type(8)));
 constexpr int KH_NQ = 128, KH_NT = 128, KH_KC = 32, KH_TP = KH_KC + 8, KH_THREADS = 512;
 constexpr int KH_MAX_DIM = 208;       // Q tile 2 x 128 x (208 + 8) halves + two T chunks + norms within 160 KB
 
-__global__ __launch_bounds__(256) void kh_absmax(const float* __restrict__ x, size_t n, unsigned* __restrict__ out_bits)
+// exponent e of the scale 2^e for a set whose largest squared row norm has these bits: no element exceeds the largest norm,
+// which the scale takes into [2^11.5, 2^12.5) (km_norms has the norms anyway; a pass for the largest element would cost more
+// than the four binades of float16 range it would gain)
+__device__ __forceinline__ int kh_scale_exp(unsigned maxn2_bits)
 {
-    float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
-    for (int o = 32; o; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));       // non-negative floats order like their bits
-}
-
-// exponent e of the scale 2^e that takes a set whose largest magnitude has these bits into [2^12, 2^13)
-__device__ __forceinline__ int kh_scale_exp(unsigned maxbits)
-{
-    const int ex = (int)((maxbits >> 23) & 255u) - 127;
-    if (maxbits == 0u || ex <= -40 || ex >= 40) return 0;       // empty / tiny / huge: unscaled (km_refine certifies nothing then)
-    return 12 - ex;
+    const int e2 = (int)((maxn2_bits >> 23) & 255u) - 127;       // largest squared norm in [2^e2, 2^(e2 + 1))
+    if (maxn2_bits == 0u || e2 <= -80 || e2 >= 80) return 0;     // empty / tiny / huge: unscaled (km_refine certifies nothing then)
+    return 12 - ((e2 + 1) >> 1);                                 // largest norm < 2^((e2 + 1) / 2) <= 2^(ex + 1/2)
 }
 
 __global__ __launch_bounds__(256) void kh_split(const float* __restrict__ x, int n, int dim, int dimp,
@@ -640,8 +638,10 @@ static int knn2_exact(ma_ctx* ctx, const float* query, int nq, const float* trai
     MaProfScope ps(ctx, MA_K_OTHER, (double)nq);
     const int split_rows = nsplit > 1 ? ((nt + nsplit - 1) / nsplit + KN_TT - 1) / KN_TT * KN_TT : nt;
     if (nsplit > 1) nsplit = (nt + split_rows - 1) / split_rows;
-    hipLaunchKernelGGL(knn2_kernel, dim3((nq + KN_TQ - 1) / KN_TQ, nsplit), dim3(256), lds, ctx->stream, query, train, nq, nt,
-                       dim, idx_out, dist_out, qlist, qcount, split_rows, part);
+    // all queries: a block per 64 of them; a list (count on the device): at most 16 blocks per train range walk it
+    const int qblocks = (nq + KN_TQ - 1) / KN_TQ;
+    hipLaunchKernelGGL(knn2_kernel, dim3(qlist ? std::min(qblocks, 16) : qblocks, nsplit), dim3(256), lds, ctx->stream, query, train,
+                       nq, nt, dim, idx_out, dist_out, qlist, qcount, split_rows, part);
     if (nsplit > 1)
         hipLaunchKernelGGL(knn2_merge_parts, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, part, nq, nsplit, qlist, qcount,
                            idx_out, dist_out);
@@ -688,7 +688,8 @@ extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const floa
                  b_part = fsplit > 1 ? (size_t)fsplit * nq * sizeof(float4) : 0;
     const int dimh = (dim + 15) & ~15;                           // split operands: rows of dimh float16
     const size_t b_qs = half16 ? ma_align_up((size_t)nq * dimh * 2, 256) : 0, b_ts = half16 ? ma_align_up((size_t)nt * dimh * 2, 256) : 0;
-    char* ws = static_cast<char*>(ma_pool_alloc(ctx, b_nt2 + b_ci + b_a4 + b_ql + 256 + b_part + 2 * b_qs + 2 * b_ts));
+    const size_t b_qn = half16 ? ma_align_up((size_t)nq * 4, 256) : 0;
+    char* ws = static_cast<char*>(ma_pool_alloc(ctx, b_nt2 + b_ci + b_a4 + b_ql + 256 + b_part + 2 * b_qs + 2 * b_ts + b_qn));
     if (!ws) return MA_ENOMEM;
     float* nt2 = reinterpret_cast<float*>(ws);
     int* cand_idx = reinterpret_cast<int*>(ws + b_nt2);
@@ -701,15 +702,16 @@ extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const floa
     char* split0 = ws + b_nt2 + b_ci + b_a4 + b_ql + 256 + b_part;
     _Float16 *qh = (_Float16*)split0, *ql = (_Float16*)(split0 + b_qs), *th = (_Float16*)(split0 + 2 * b_qs),
              *tl = (_Float16*)(split0 + 2 * b_qs + b_ts);
+    float* qn2 = reinterpret_cast<float*>(split0 + 2 * b_qs + 2 * b_ts);
     int rc = MA_OK;
     do {
         if (hipMemsetAsync(tmax, 0, 16, ctx->stream) != hipSuccess) { rc = MA_EHIP; break; }
         if (half16) {
             MaProfScope ps(ctx, MA_K_OTHER, (double)nq);
             hipLaunchKernelGGL(km_norms, dim3((nt + 255) / 256), dim3(256), 0, ctx->stream, train, nt, dim, nt2, tmax);
-            const size_t eq = (size_t)nq * dim, et = (size_t)nt * dim;
-            hipLaunchKernelGGL(kh_absmax, dim3((unsigned)std::min<size_t>(1024, (eq + 255) / 256)), dim3(256), 0, ctx->stream, query, eq, amax);
-            hipLaunchKernelGGL(kh_absmax, dim3((unsigned)std::min<size_t>(1024, (et + 255) / 256)), dim3(256), 0, ctx->stream, train, et, amax + 1);
+            // the queries' norms set their scale (amax[0]); the train rows' are km_norms' tmax, copied beside it (amax[1])
+            hipLaunchKernelGGL(km_norms, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, query, nq, dim, qn2, amax);
+            if (hipMemcpyAsync(amax + 1, tmax, sizeof(unsigned), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) { rc = MA_EHIP; break; }
             hipLaunchKernelGGL(kh_split, dim3((unsigned)(((size_t)nq * dimh + 255) / 256)), dim3(256), 0, ctx->stream, query, nq, dim, dimh,
                                (const unsigned*)amax, qh, ql);
             hipLaunchKernelGGL(kh_split, dim3((unsigned)(((size_t)nt * dimh + 255) / 256)), dim3(256), 0, ctx->stream, train, nt, dim, dimh,
