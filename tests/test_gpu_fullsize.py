@@ -23,6 +23,8 @@ from microaligner_amd import OptFlowRegistrator, Warper, synthetic
 
 pytestmark = pytest.mark.gpu
 CORES = os.cpu_count() or 1
+from conftest import oracle_threads  # noqa: E402
+THREADS = oracle_threads()     # what the oracle runs with: the CPU quota, not the 256 hardware threads the box shows
 BIG_HOST = CORES >= int(os.environ.get("MA_FULLSIZE_MIN_CORES", "64"))
 
 
@@ -48,7 +50,7 @@ def _compare(ref, mov, params, label, models=None):
     t0 = time.perf_counter()
     flow, reports, warped = _hip(ref, mov, hip_params)
     t1 = time.perf_counter()
-    exp_flow, exp_rep = RO.register(ref, mov, nthreads=CORES, **orc_params)
+    exp_flow, exp_rep = RO.register(ref, mov, nthreads=THREADS, **orc_params)
     exp_warp = RO.warp(mov, exp_flow, params.get("tile_size", 1000), params.get("overlap", 100))
     t2 = time.perf_counter()
     print(f"\n[{label}] HIP {t1 - t0:.2f} s (numpy in/out, cold), oracle {t2 - t1:.1f} s on {CORES} threads; levels "
@@ -149,7 +151,7 @@ def test_cfg5_mosaic_tiles_affine_init_then_optical_flow_refine():
         assert final.dtype == np.uint16 and flow.shape == (H, W, 2)
     ref, mov, _ = tiles[0]
     affine = transform_img_with_tmat(mov, (H, W), out[0][1])
-    exp_flow, _ = RO.register(ref, affine, nthreads=CORES, **of_params)
+    exp_flow, _ = RO.register(ref, affine, nthreads=THREADS, **of_params)
     assert np.array_equal(out[0][2], exp_flow)
     assert np.array_equal(out[0][0], RO.warp(affine, exp_flow, 1000, 100))
 
@@ -217,7 +219,7 @@ def test_cfg4_cycle_chain_at_8192_equals_the_oracle_pipeline():
     assert np.array_equal(aligned[0], cycles[0]) and flows[0] is None
     for cyc in (1, 2):
         mov = conditioned(cycles[cyc])
-        flow, _ = RO.register(ref, mov, nthreads=CORES, **params)
+        flow, _ = RO.register(ref, mov, nthreads=THREADS, **params)
         assert np.array_equal(flows[cyc], flow), cyc
         ref = RO.warp(mov, flow, 1000, 100)
         for z in range(2):

@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import oracle_threads
+
 from oracle import oracle as O
 from oracle import register_oracle as RO
 from microaligner_amd import OptFlowRegistrator, Warper, synthetic
@@ -48,7 +50,7 @@ def test_primitives_on_a_strip_taller_than_the_grid_limit(ctx, strip):
     assert np.array_equal(ctx.dog_u8(dmov).numpy(), O.dog(mov))
     # tiled Farneback, warp, merge: whole image against the oracle
     flow = ctx.farneback(dmov, dref, 51, 2, tile=TILE, overlap=OV)
-    exp_flow = RO.tile_flow(ref, mov, TILE, OV, 51, 2, nthreads=os.cpu_count())
+    exp_flow = RO.tile_flow(ref, mov, TILE, OV, 51, 2, nthreads=oracle_threads())
     got_flow = flow.numpy()
     assert np.array_equal(got_flow, exp_flow)
     assert np.abs(got_flow[65536:]).max() > 0                      # the rows beyond the old bound carry a real flow
@@ -68,7 +70,7 @@ def test_primitives_on_a_strip_taller_than_the_grid_limit(ctx, strip):
 def test_register_and_warp_on_a_strip_taller_than_the_grid_limit(ctx, strip):
     ref, mov = strip
     params = dict(num_pyr_lvl=2, use_full_res_img=True, use_dog=True, tile_size=TILE, overlap=OV, num_iterations=2)
-    exp, reports = RO.register(ref, mov, nthreads=os.cpu_count(), **params)
+    exp, reports = RO.register(ref, mov, nthreads=oracle_threads(), **params)
     got = {}
     for engine in ("c", "python"):
         reg = OptFlowRegistrator()
