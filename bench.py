@@ -734,8 +734,8 @@ def main():
                          "Warper.warp_pages, pageable and page-locked buffers) at the same time and the line reports them per "
                          "rank with the whole-node rates (`host_modes`); auto: when N > 1 -- the modes that can fail to "
                          "scale -- at N = 1 the `variants` legs cover them")
-    ap.add_argument("--host-mode-pairs", type=int, default=4, help="pairs per rank of the stream_pairs host modes")
-    ap.add_argument("--host-mode-pages", type=int, default=4, help="uint16 pages per rank of the warp_pages host modes")
+    ap.add_argument("--host-mode-pairs", type=int, default=8, help="pairs per rank of the stream_pairs host modes")
+    ap.add_argument("--host-mode-pages", type=int, default=8, help="uint16 pages per rank of the warp_pages host modes")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduce plumbing only, no GPU work (CPU test of the N-rank launcher)")
     args = ap.parse_args()

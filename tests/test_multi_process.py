@@ -88,7 +88,7 @@ def test_bench_eight_ranks_report_per_rank_rows_and_deal_pairs_round_robin():
     for mode in ("stream_pairs_pageable", "stream_pairs_page_locked", "warp_pages_pageable", "warp_pages_page_locked"):
         row = hm[mode]
         assert len(row["ms_per_unit_per_rank"]) == 8 and len(row["buffers_moved_directly"]) == 8
-        assert row["aggregate_mpix_s"] > 0 and row["units_per_rank"] == 4
+        assert row["aggregate_mpix_s"] > 0 and row["units_per_rank"] == 8
         assert row["buffers_moved_directly"] == [mode.endswith("locked")] * 8
         slowest = max(row["ms_per_unit_per_rank"]) * row["units_per_rank"] / 1e3
         assert row["aggregate_mpix_s"] == pytest.approx(8 * row["units_per_rank"] * 1e6 / slowest / 1e6, rel=1e-2)
