@@ -3,9 +3,10 @@
 2x3 float64 matrix that maps the moving image onto the reference.
 
 Division of labour: pyramid (cv2.pyrDown), dog(), the image transforms (cv2.warpAffine up to
-32000 px, scikit-image's warp above), the mutual-information gate, the FAST score map, the DAISY descriptors and the
-2-NN search are HIP kernels behind the C-ABI; picking corners, the ratio test and RANSAC (a few thousand points) run
-on the host (feature_detection.py / sparse_cpu.py).  The public surface mirrors the reference; the machinery below it
+32000 px, scikit-image's warp above), the mutual-information gate, the feature extraction of a level (windows, FAST,
+corner selection, DAISY: ma_feature_extract), the 2-NN search, the ratio test and the RANSAC similarity fit
+(ma_knn2_l2, ma_match_similarity) are HIP kernels behind the C-ABI; the host keeps the level loop and its decisions
+(feature_detection.py; sparse_cpu.py is the host statement the kernels reproduce bit for bit).  The public surface mirrors the reference; the machinery below it
 is this package's own: one `_Level` record per pyramid level, one `_register_level` pass per level.
 """
 from dataclasses import dataclass

@@ -7,11 +7,13 @@ q_radius=3, q_theta=8, q_hist=8, NRM_NONE, interpolation=True, use_orientation=F
 Lowe's ratio 0.5, cv.estimateAffinePartial2D(RANSAC, confidence=0.99).  opencv-contrib is not available to this
 build, so the stage is restated here from the published algorithms.  This module is the HOST statement of that
 stage and the definition its device counterparts are tested against: csrc/daisy.hip (FAST score map + non-maximum
-suppression, DAISY layers / smoothing / sampling, all tiles of a level in one batch) and csrc/knn.hip (the exact 2-NN
-search) reproduce it bit for bit and are what FeatureRegistrator runs; corner selection, the ratio test and RANSAC --
-a few thousand points -- stay here.  PARITY UNPINNED: FAST follows OpenCV's segment test, score and 3x3 non-maximum suppression exactly
+suppression, corner selection, DAISY layers / smoothing / sampling, all tiles of a level in one call), csrc/knn.hip (the
+exact 2-NN search) and csrc/ransac.hip (ratio test, RANSAC similarity fit) reproduce it bit for bit and are what
+FeatureRegistrator runs; this file serves host arrays (tiles that are not uint8 device images, coordinates that are not
+integer-valued) and the tests.  PARITY UNPINNED: FAST follows OpenCV's segment test, score and 3x3 non-maximum suppression exactly
 as published; DAISY follows Tola et al. (PAMI 2010) with OpenCV's parameter meaning but not its exact smoothing
-schedule; matching is exact 2-NN where FLANN is approximate; RANSAC uses its own random sequence.  The outputs are
+schedule; matching is exact 2-NN where FLANN is approximate; RANSAC uses numpy's seeded sequence and closed-form fits where OpenCV has its
+own generator and a Levenberg-Marquardt refinement.  The outputs are
 therefore functionally equivalent (same kind of keypoints, descriptors and 2x3 similarity transform), not
 bit-identical to opencv-contrib.
 """
