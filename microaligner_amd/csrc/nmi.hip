@@ -81,62 +81,58 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// One block of 1024 threads per chunk: thread (q, j) owns column j of the rows [64q, 64q+64) of the chunk's
-// histogram, so the 2 x 65536 double-precision logarithms of a chunk are spread over 16 waves.
-constexpr int NR_T = 1024;
-// block b: histogram b, chunk b % nchunks (the histograms of a second label image follow those of the first)
+// Four blocks of 256 threads per chunk histogram (blockIdx.y = q): thread j of block q owns column j of the rows [64q, 64q+64),
+// so the 2 x 65536 double-precision logarithms of a chunk are spread over 16 waves -- as in the single block of 1024 threads of
+// rounds 1 - 5, whose placement needed sixteen free wave slots on ONE CU at once and waited 380 us on average (107 alone) for
+// the companion stream's dog() blocks to leave (profiles/r06_kernel_stats_cfg3_companion_on.csv).  Each wave leaves its partial
+// sums in `part`; nmi_final_kernel adds them in the order the single block used (wave 0 .. 15), so the scores keep their bits.
+constexpr int NR_T = 256, NR_Q = 4;
+// per histogram: [0..15] mutual-information partials (wave 4q + w), [16..19] / [20..23] entropy partials of a / b (the waves of
+// block 0), [24..27] / [28..31] number of non-empty labels of a among the block's rows / of b (block 0 only counts them)
+constexpr int NR_PART = 32;
+// block (b, q): histogram b, chunk b % nchunks (the histograms of a second label image follow those of the first)
 __global__ __launch_bounds__(NR_T) void nmi_reduce_kernel(const unsigned* __restrict__ hist, size_t n, size_t chunk,
-                                                          unsigned nchunks, double* __restrict__ scores)
+                                                          unsigned nchunks, double* __restrict__ part)
 {
-    __shared__ unsigned paq[4][256], pbq[4][256];
-    __shared__ unsigned pa[256], pb[256];
-    __shared__ double red[NR_T / 64];
+    __shared__ unsigned pa[64], pb[256];
     __shared__ int cnt[2];
     const unsigned* hh = hist + (size_t)blockIdx.x * 65536;
-    const int t = threadIdx.x, j = t & 255, q = t >> 8, lane = t & 63, w = t >> 6;
+    const int j = threadIdx.x, q = blockIdx.y, lane = j & 63, w = j >> 6;
     const size_t c0 = (size_t)(blockIdx.x % nchunks) * chunk;
     const double N = (double)((c0 + chunk < n ? c0 + chunk : n) - c0);
+    double* out = part + (size_t)blockIdx.x * NR_PART;
 
-    if (t < 2) cnt[t] = 0;
-    // marginals (counts < 2^32 by the chunk limit): column j over this thread's rows (coalesced across the wave)
-    // and a quarter of row j (16 independent 16-byte loads)
+    if (j < 2) cnt[j] = 0;
+    // marginals (counts < 2^32 by the chunk limit): column j over ALL rows (coalesced across the wave), and -- threads 0 .. 63 --
+    // row 64 q + j (64 independent 16-byte loads)
     {
         unsigned sb = 0;
 #pragma unroll 16
-        for (int r = 0; r < 64; r++) sb += hh[(64 * q + r) * 256 + j];
-        pbq[q][j] = sb;
-        const uint4* row = reinterpret_cast<const uint4*>(hh + j * 256 + 64 * q);
-        unsigned sa = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) { uint4 v = row[k]; sa += v.x + v.y + v.z + v.w; }
-        paq[q][j] = sa;
+        for (int r = 0; r < 256; r++) sb += hh[r * 256 + j];
+        pb[j] = sb;
+        if (j < 64) {
+            const uint4* row = reinterpret_cast<const uint4*>(hh + (64 * q + j) * 256);
+            unsigned sa = 0;
+#pragma unroll 16
+            for (int k = 0; k < 64; k++) { uint4 v = row[k]; sa += v.x + v.y + v.z + v.w; }
+            pa[j] = sa;
+        }
     }
     __syncthreads();
-    if (q == 0) {
-        const unsigned a = paq[0][j] + paq[1][j] + paq[2][j] + paq[3][j];
-        const unsigned b = pbq[0][j] + pbq[1][j] + pbq[2][j] + pbq[3][j];
-        pa[j] = a; pb[j] = b;
-        if (a > 0) atomicAdd(&cnt[0], 1);
-        if (b > 0) atomicAdd(&cnt[1], 1);
-    }
+    if (j < 64 && pa[j] > 0) atomicAdd(&cnt[0], 1);
+    if (q == 0 && pb[j] > 0) atomicAdd(&cnt[1], 1);
     __syncthreads();
-    const int ca = cnt[0], cb = cnt[1];
-    if (ca == 1 && cb == 1) {  // both label sets have a single value
-        if (t == 0) scores[blockIdx.x] = 1.0;
-        return;
-    }
     const double logN = log(N);
     const unsigned long long pbj = pb[j];
     double mi = 0.0;
     if (pbj > 0) {
 #pragma unroll 8
         for (int rr = 0; rr < 64; rr++) {
-            const int r = 64 * q + rr;
-            unsigned nij = hh[r * 256 + j];
+            unsigned nij = hh[(64 * q + rr) * 256 + j];
             if (nij) {
                 double log_nm = log((double)nij);
                 double nm = (double)nij / N;
-                double outer = (double)((long long)pa[r] * (long long)pbj);
+                double outer = (double)((long long)pa[rr] * (long long)pbj);
                 double log_outer = -log(outer) + logN + logN;
                 double term = nm * (log_nm - logN) + nm * log_outer;
                 if (fabs(term) < DBL_EPSILON) term = 0.0;
@@ -144,34 +140,45 @@ __global__ __launch_bounds__(NR_T) void nmi_reduce_kernel(const unsigned* __rest
             }
         }
     }
-    // entropies: thread (0, j) contributes label j of each side
+    mi = wave_sum(mi);
+    if (lane == 0) out[4 * q + w] = mi;
+    // entropies: label j of a is row j of the histogram -- block j / 64 holds its marginal (thread j % 64); label j of b: block 0
     double ha = 0.0, hb = 0.0;
-    if (q == 0) {
-        if (pa[j] > 0) ha = ((double)pa[j] / N) * (log((double)pa[j]) - logN);
-        if (pbj > 0) hb = ((double)pbj / N) * (log((double)pbj) - logN);
+    if (j < 64 && pa[j] > 0) ha = ((double)pa[j] / N) * (log((double)pa[j]) - logN);
+    if (q == 0 && pbj > 0) hb = ((double)pbj / N) * (log((double)pbj) - logN);
+    // the single block summed ha over its waves 0 .. 3 = labels 0 .. 255 in runs of 64: here run q is wave 0 of block q
+    ha = wave_sum(ha);
+    hb = wave_sum(hb);
+    if (lane == 0) {
+        if (w == 0) out[16 + q] = ha;
+        if (q == 0) out[20 + w] = hb;
     }
-    double vals[3] = {mi, ha, hb}, tot[3];
-    for (int k = 0; k < 3; k++) {
-        double s = wave_sum(vals[k]);
-        if (lane == 0) red[w] = s;
-        __syncthreads();
-        double a = 0.0;
-        for (int i = 0; i < NR_T / 64; i++) a += red[i];
-        tot[k] = a;
-        __syncthreads();
+    if (j == 0) {
+        out[24 + q] = (double)cnt[0];
+        if (q == 0) out[28] = (double)cnt[1];
     }
-    if (t == 0) {
-        double m = tot[0] < 0 ? 0.0 : tot[0];
-        double score;
-        if (fabs(m) < DBL_EPSILON) score = 0.0;
-        else {
-            double h_a = ca == 1 ? 0.0 : -tot[1], h_b = cb == 1 ? 0.0 : -tot[2];
-            double norm = 0.5 * (h_a + h_b);
-            if (norm < DBL_EPSILON) norm = DBL_EPSILON;
-            score = m / norm;
-        }
-        scores[blockIdx.x] = score;
+}
+
+__global__ __launch_bounds__(64) void nmi_final_kernel(const double* __restrict__ part, unsigned nhist, double* __restrict__ scores)
+{
+    const unsigned b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= nhist) return;
+    const double* p = part + (size_t)b * NR_PART;
+    const int ca = (int)(p[24] + p[25] + p[26] + p[27]), cb = (int)p[28];
+    if (ca == 1 && cb == 1) { scores[b] = 1.0; return; }      // both label sets have a single value
+    double tot[3] = {0.0, 0.0, 0.0};
+    for (int i = 0; i < 16; i++) tot[0] += p[i];
+    for (int i = 0; i < 4; i++) { tot[1] += p[16 + i]; tot[2] += p[20 + i]; }
+    double m = tot[0] < 0 ? 0.0 : tot[0];
+    double score;
+    if (fabs(m) < DBL_EPSILON) score = 0.0;
+    else {
+        double h_a = ca == 1 ? 0.0 : -tot[1], h_b = cb == 1 ? 0.0 : -tot[2];
+        double norm = 0.5 * (h_a + h_b);
+        if (norm < DBL_EPSILON) norm = DBL_EPSILON;
+        score = m / norm;
     }
+    scores[b] = score;
 }
 
 } // namespace
@@ -189,10 +196,11 @@ int ma_nmi_u8_enqueue2(ma_ctx* ctx, const uint8_t* a, const uint8_t* b0, const u
     MA_REQUIRE(chunk < ((size_t)1 << 32), "chunk must be < 2^32 elements");
     MA_HIP(hipSetDevice(ctx->device));
     const size_t hist_bytes = nimg * nchunks * 65536 * sizeof(unsigned);
-    const size_t total = hist_bytes + nimg * nchunks * sizeof(double);
+    const size_t total = hist_bytes + nimg * nchunks * (1 + NR_PART) * sizeof(double);
     MA_TRY(ma_ws_reserve(ctx, total));
     unsigned* hist = (unsigned*)ctx->ws;
     double* scores = (double*)((char*)ctx->ws + hist_bytes);
+    double* part = scores + nimg * nchunks;
     {
         MaProfScope ps(ctx, MA_K_NMI, (double)n * nimg);
         MA_HIP(hipMemsetAsync(hist, 0, hist_bytes, ctx->stream));
@@ -207,8 +215,10 @@ int ma_nmi_u8_enqueue2(ma_ctx* ctx, const uint8_t* a, const uint8_t* b0, const u
         else
             hipLaunchKernelGGL((joint_hist16_kernel<1024, 1>), dim3((unsigned)slices, (unsigned)nchunks, nimg), dim3(1024),
                                32768 * sizeof(unsigned), ctx->stream, a, b0, b1, n, chunk, hist);
-        hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)(nimg * nchunks)), dim3(NR_T), 0, ctx->stream, hist, n, chunk,
-                           (unsigned)nchunks, scores);
+        hipLaunchKernelGGL(nmi_reduce_kernel, dim3((unsigned)(nimg * nchunks), NR_Q), dim3(NR_T), 0, ctx->stream, hist, n, chunk,
+                           (unsigned)nchunks, part);
+        hipLaunchKernelGGL(nmi_final_kernel, dim3((unsigned)((nimg * nchunks + 63) / 64)), dim3(64), 0, ctx->stream,
+                           (const double*)part, (unsigned)(nimg * nchunks), scores);
         MA_HIP(hipGetLastError());
     }
     MA_HIP(hipMemcpyAsync(scores0_pinned_host, scores, nchunks * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
