@@ -544,12 +544,13 @@ def host_modes_measure(ctx, ref, mov, params, n_pairs, n_pages, sync):
 
         def timed():
             ctx.transfer_stats(reset=True)
-            t0 = time.perf_counter()
+            c0, t0 = time.process_time(), time.perf_counter()
             for _ in parallel.stream_pairs(seq, params, warp=True, out=lambda i: outs[i % 2]):
                 pass
-            dt = time.perf_counter() - t0
+            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
             up, down = ctx.transfer_stats(reset=True)
-            res[tag] = {"units": n_pairs, "unit": "pair", "seconds": dt, "payload_bytes": int(up + down),
+            res[tag] = {"units": n_pairs, "unit": "pair", "seconds": dt, "payload_bytes": int(up + down), "host_cpu_seconds": cpu,
+                        "mode_in": device.transfer_mode(ins[0][0]), "mode_out": device.transfer_mode(outs[0][0]),
                         "direct_in": device.transfer_is_direct(ins[0][0]), "direct_out": device.transfer_is_direct(outs[0][0])}
         guarded(tag, warm)
         sync()
@@ -557,6 +558,7 @@ def host_modes_measure(ctx, ref, mov, params, n_pairs, n_pages, sync):
         sync()
 
     stream("stream_pairs_pageable")
+    res["transient_page_locking"] = device.transient_pin_stats()       # what the pageable mode did with the caller's arrays
     t0 = time.perf_counter()
     locked = [a for pair in ins + outs for a in pair]
     ok = all([device.host_register(a) for a in locked])
@@ -581,11 +583,13 @@ def host_modes_measure(ctx, ref, mov, params, n_pairs, n_pages, sync):
     def paged(tag):
         def timed():
             ctx.transfer_stats(reset=True)
-            t0 = time.perf_counter()
+            c0, t0 = time.process_time(), time.perf_counter()
             w.warp_pages(pages, pout)
-            dt = time.perf_counter() - t0
+            dt, cpu = time.perf_counter() - t0, time.process_time() - c0
             up, down = ctx.transfer_stats(reset=True)
-            res[tag] = {"units": n_pages, "unit": "uint16 page", "seconds": dt, "payload_bytes": int(up + down),
+            res[tag] = {"units": n_pages, "unit": "uint16 page", "seconds": dt, "payload_bytes": int(up + down), "host_cpu_seconds": cpu,
+                        "mode_in": "direct" if device.transfer_is_direct(pages[0]) else "staged (pieces: no transient page-locking)",
+                        "mode_out": "direct" if device.transfer_is_direct(pout[0]) else "staged (pieces: no transient page-locking)",
                         "direct_in": device.transfer_is_direct(pages[0]), "direct_out": device.transfer_is_direct(pout[0])}
         guarded(tag, lambda: w.warp_pages(pages[:2], pout[:2]))
         sync()
@@ -618,9 +622,14 @@ def host_modes_report(rows, H, W):
                      "ms_per_unit_per_rank": [round(p["seconds"] / p["units"] * 1e3, 2) for p in per],
                      "aggregate_mpix_s": round(units * H * W / slowest / 1e6, 1),
                      "aggregate_payload_gb_s": round(sum(p["payload_bytes"] for p in per) / slowest / 1e9, 1),
-                     "buffers_moved_directly": [bool(p["direct_in"] and p["direct_out"]) for p in per]}
+                     "buffers_moved_directly": [bool(p["direct_in"] and p["direct_out"]) for p in per],
+                     "transfer_mode_in_out": [f"{p.get('mode_in')} / {p.get('mode_out')}" for p in per],
+                     "host_cpu_s_per_unit_per_rank": [round(p.get("host_cpu_seconds", 0.0) / p["units"], 4) for p in per]}
         if "registered_in_place" in per[0]:
             out[mode]["registered_in_place"] = [bool(p["registered_in_place"]) for p in per]
+    tp = [r.get("transient_page_locking") for r in rows if r.get("transient_page_locking") is not None]
+    if tp:
+        out["transient_page_locking_per_rank"] = tp
     reg = [r.get("host_register_ms_per_gib") for r in rows if r.get("host_register_ms_per_gib") is not None]
     if reg:
         out["host_register_ms_per_gib"] = reg
@@ -813,7 +822,8 @@ def main():
                     dist.barrier()
                 n = args.host_mode_pairs if mode.startswith("stream") else args.host_mode_pages
                 row[mode] = {"units": n, "unit": "pair" if mode.startswith("stream") else "uint16 page",
-                             "seconds": 1e-3 * n * (k + 1) * (1 + 0.01 * rank), "payload_bytes": 1000 * n,
+                             "seconds": 1e-3 * n * (k + 1) * (1 + 0.01 * rank), "payload_bytes": 1000 * n, "host_cpu_seconds": 1e-4 * n,
+                             "mode_in": "direct" if mode.endswith("locked") else "staged", "mode_out": "direct" if mode.endswith("locked") else "staged",
                              "direct_in": mode.endswith("locked"), "direct_out": mode.endswith("locked")}
             row["host_register_ms_per_gib"] = 100.0
         rows = rank_table(dist, world, rank, row)
@@ -1056,7 +1066,7 @@ def main():
             errs = [r["host_modes_error"] for r in rows if "host_modes_error" in r]
             res["host_modes"] = {"error": errs} if errs else host_modes_report(rows, H, W)
             for r in rows:       # the per-rank rows stay compact: the modes are reported above
-                for k in HOST_MODES + ("host_register_ms_per_gib", "host_modes_error"):
+                for k in HOST_MODES + ("host_register_ms_per_gib", "host_modes_error", "transient_page_locking"):
                     r.pop(k, None)
         def informational(store, name, fn):
             """An informational leg never costs the headline line: a failure is recorded in its place."""

@@ -158,8 +158,15 @@ int ma_host_unregister(void* hptr);
 /* How a transfer of [hptr, hptr + bytes) will be carried out: *direct = 1 when the WHOLE range is page-locked (inside one
  * ma_host_register registration, or inside one allocation the HIP runtime reports as host memory) and goes by DMA as it
  * is; 0 when any part of it is pageable or of unknown extent -- e.g. a copy that starts inside a registered row of a shared
- * array and runs past its end -- and the transfer is staged through the ctx's page-locked ring. */
+ * array and runs past its end -- and the transfer is staged through the ctx's page-locked ring; 2 when a blocking copy of
+ * the range would page-lock it for its own duration (opt-in, MICROALIGNER_TRANSIENT_PIN=1, arrays of >= 64 MiB:
+ * hipHostRegister, one DMA, hipHostUnregister -- one pass over host DRAM instead of the staged path's three to four, at
+ * the price of the registration). */
 int ma_host_transfer_is_direct(const void* hptr, size_t bytes, int* direct);
+/* Process-wide account of the transient page-locking: copies carried out under a registration of their own, how many of their
+ * registrations were slower than 30 ms per GiB, the time spent registering and the volume, and whether the mechanism is (still)
+ * active for big arrays in this process. */
+int ma_transient_pin_stats(long long* copies, long long* slow_registrations, double* register_ms, double* gib, int* active);
 int ma_memset(ma_ctx* ctx, void* dst, int value, size_t bytes);
 
 /* ---- timing (HIP events on the ctx stream) ------------------------------ */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "ma_host_register": (_i, [_vp, _sz]),
     "ma_host_unregister": (_i, [_vp]),
     "ma_host_transfer_is_direct": (_i, [_vp, _sz, C.POINTER(C.c_int)]),
+    "ma_transient_pin_stats": (_i, [C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(_d), C.POINTER(_d), C.POINTER(C.c_int)]),
     "ma_memset": (_i, [_vp, _vp, _i, _sz]),
     "ma_event_create": (_i, [_vp, C.POINTER(_vp)]),
     "ma_event_destroy": (_i, [_vp, _vp]),

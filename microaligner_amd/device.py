@@ -1095,15 +1095,29 @@ def host_unregister(arr):
     return False
 
 
-def transfer_is_direct(arr):
-    """Whether a transfer to / from the whole of `arr` goes by DMA as it is (page-locked over its full extent) or through
-    the staging ring (ma_host_transfer_is_direct)."""
+def transfer_mode(arr):
+    """How a blocking transfer to / from the whole of `arr` is carried out (ma_host_transfer_is_direct): "direct" -- page-locked
+    over its full extent, DMA as it is; "transient" -- pageable, but the copy page-locks the range for its own duration (opt-in:
+    MICROALIGNER_TRANSIENT_PIN=1, arrays of >= 64 MiB); "staged" -- through the page-locked ring."""
     a = np.asarray(arr)
     if a.nbytes == 0:
-        return False
+        return "staged"
     out = C.c_int(0)
     L.check(L.load().ma_host_transfer_is_direct(C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), C.byref(out)))
-    return bool(out.value)
+    return {1: "direct", 2: "transient"}.get(out.value, "staged")
+
+
+def transient_pin_stats():
+    """dict(copies, slow_registrations, register_ms, gib, active) of the transient page-locking in this process
+    (ma_transient_pin_stats)."""
+    c, sl, ms, gib, act = C.c_longlong(), C.c_longlong(), C.c_double(), C.c_double(), C.c_int()
+    L.check(L.load().ma_transient_pin_stats(C.byref(c), C.byref(sl), C.byref(ms), C.byref(gib), C.byref(act)))
+    return dict(copies=c.value, slow_registrations=sl.value, register_ms=ms.value, gib=gib.value, active=bool(act.value))
+
+
+def transfer_is_direct(arr):
+    """Whether a transfer to / from the whole of `arr` goes by DMA as it is (page-locked over its full extent)."""
+    return transfer_mode(arr) == "direct"
 
 
 _STAGED_WARNED = [False]
@@ -1118,7 +1132,7 @@ def _warn_if_staged_on_a_full_node(arr):
         ws = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
     except ValueError:
         return
-    if ws >= 3 and not transfer_is_direct(arr):
+    if ws >= 3 and transfer_mode(arr) == "staged":
         import warnings
         _STAGED_WARNED[0] = True
         warnings.warn(f"microaligner_amd: a pageable {arr.nbytes >> 20} MiB array is going through the staged copy path with "

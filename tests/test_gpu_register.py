@@ -958,3 +958,42 @@ def test_two_ranks_download_into_their_own_page_locked_rows(tmp_path):
     for row in res:
         assert row["ok"] and row["locked"]
         assert all(row["direct_own"]) and not any(row["direct_other"]) and row["direct_span"] is False
+
+
+def test_transient_page_locking_of_big_pageable_arrays(ctx):
+    """MICROALIGNER_TRANSIENT_PIN=1 (opt-in): a blocking copy of a pageable array of
+    >= 64 MiB page-locks the caller's range for its own duration -- hipHostRegister, one DMA, hipHostUnregister -- instead of
+    staging it.  In a child process (the policy is read once per process): bytes arrive in both directions, the library
+    reports the mode, nothing stays registered (a permanent registration of the same array succeeds afterwards), smaller arrays
+    and ranges that cannot be registered (part of them registered already) are staged as before."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, ctypes as C
+from microaligner_amd import device, _lib as L
+from microaligner_amd.device import get_context
+ctx = get_context()
+rng = np.random.default_rng(3)
+big = rng.integers(0, 255, (9000, 9000), dtype=np.uint8)                 # 81 MB, pageable
+small = rng.integers(0, 255, (3000, 3000), dtype=np.uint8)               # 9 MB: below the threshold
+assert device.transfer_mode(big) == "transient" and device.transfer_mode(small) == "staged"
+d = ctx.asdevice(big)
+back = np.empty_like(big)
+d.numpy(out=back)
+assert np.array_equal(back, big)
+assert device.transfer_mode(big) == "transient"                          # nothing was left registered ...
+assert device.host_register(big) is True and device.transfer_mode(big) == "direct"   # ... a permanent registration still works
+assert device.host_unregister(big)
+# a range that is partly registered already cannot be registered again: staged, bytes still right
+half = big[:4500]
+assert device.host_register(half) is True
+d2 = ctx.empty(big.shape, big.dtype)
+L.check(L.load().ma_memcpy_h2d(ctx.handle, d2.ptr, C.c_void_p(big.ctypes.data), C.c_size_t(big.nbytes)))
+assert np.array_equal(d2.numpy(), big)
+device.host_unregister(half)
+print("ok")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MICROALIGNER_TRANSIENT_PIN="1", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
