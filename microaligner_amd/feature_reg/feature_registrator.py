@@ -46,6 +46,8 @@ class FeatureRegistrator:
         self.verbose = True      # addition: the reference prints unconditionally
         self.compat_mov_getter = True   # the mov_img getter returns the REFERENCE image, as the reference's does; False: the moving image
         self._levels: List[_Level] = []   # reference side, coarsest first; kept for register(reuse_ref_img=True)
+        self.features_on_host = False     # True: features and matching by the HOST statement (sparse_cpu.py, the definition the
+        #                                     kernels reproduce; slow) -- dense steps stay on the device.  For cross-checks
         self._careful = False             # True: register() runs in the careful mode only (see register())
         self._fast = False                # True while register()'s fast attempt runs: dog() defers its max() == 0 report
         self._log_buf = None              # log lines of the fast attempt that no synchronisation point has confirmed yet
@@ -197,10 +199,10 @@ class FeatureRegistrator:
         ctx = get_context()
         if pre is None:
             pre = self.dog(img, self.use_dog)
-        if isinstance(pre, DeviceArray) and pre.dtype == np.uint8:
+        if isinstance(pre, DeviceArray) and pre.dtype == np.uint8 and not self.features_on_host:
             return find_features_of_device_image(pre, self.tile_size, ctx)
         host = pre.numpy() if isinstance(pre, DeviceArray) else np.asarray(pre)
-        return find_features(host, self.tile_size, ctx)
+        return find_features(host, self.tile_size, None if self.features_on_host else ctx)
 
     def _register_level(self, ref_level: _Level, mov_level) -> np.ndarray:
         """:162-207: `num_iterations` rounds on one level.  A round estimates the similarity that maps the current
@@ -223,7 +225,11 @@ class FeatureRegistrator:
             # the exact 2-NN search over up to 45 000 x 45 000 descriptors, the ratio test and the RANSAC fit run on the device
             # (ma_knn2_l2, ma_match_similarity): the matrix and the match count come back
             mov_features = self._features_of(current, pre=current_gate if self.use_dog else None)
-            estimate = register_img_pair(ref_level.features, mov_features, self.verbose, log=self._log, ctx=ctx)
+            if self.features_on_host:
+                from .sparse_cpu import knn2_sequential
+                estimate = register_img_pair(ref_level.features, mov_features, self.verbose, knn=knn2_sequential, log=self._log)
+            else:
+                estimate = register_img_pair(ref_level.features, mov_features, self.verbose, log=self._log, ctx=ctx)
             is_identity = bool(np.array_equal(estimate, affine_math.IDENTITY))
             candidate = current if is_identity else self.transform_img(current, estimate)
             candidate_gate = current_gate if is_identity else self.dog(candidate, True)

@@ -720,3 +720,36 @@ def test_feature_registrator_reproduces_the_reference_orchestration(name):
     mi = [(float(a), float(b)) for a, b in re.findall(r"MI score after: (\S+) \| MI score before: (\S+)", log)]
     assert np.allclose(mi, case["mi"], rtol=0, atol=1e-12)
     assert np.allclose(T, np.array(case["t_mat"]), rtol=0, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [301, 308, 317])
+def test_feature_registrator_device_path_equals_the_host_statement(seed):
+    """End to end: register() with the feature stage on the device (ma_feature_extract, ma_knn2_l2 with the split-float16
+    shortlist, ma_match_similarity) against the same registrator with `features_on_host` -- FAST, DAISY, the sequential exact
+    2-NN, ratio test and RANSAC of feature_reg/sparse_cpu.py, the definition the kernels reproduce: the same matrix, bit for bit,
+    and the same log (levels, match counts, scores, decisions).  tools/soak_feature.py runs 30 such configurations."""
+    import contextlib
+    import io
+    from microaligner_amd import FeatureRegistrator
+    rng = np.random.default_rng(seed)
+    H, W = int(rng.integers(420, 760)), int(rng.integers(420, 760))
+    dtype = [np.uint8, np.uint16, np.float32][seed % 3]
+    ref = synthetic.make_cells(H, W, seed=seed, dtype=dtype)
+    th = np.deg2rad(rng.uniform(-1.0, 1.0))
+    M = np.array([[np.cos(th), -np.sin(th), rng.uniform(-12, 12)], [np.sin(th), np.cos(th), rng.uniform(-12, 12)]])
+    if seed % 2:
+        M = np.array([[1.0, 0.0, 7.0], [0.0, 1.0, -5.0]])         # exact integer shift: residuals exactly on the RANSAC threshold
+    mov = O.warp_affine(ref, M)
+    out = []
+    for host in (False, True):
+        f = FeatureRegistrator()
+        f.num_pyr_lvl, f.num_iterations, f.tile_size, f.use_full_res_img = 1, 2, 300, bool(seed % 2)
+        f.features_on_host = host
+        f.ref_img, f.mov_img = ref, mov
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            T = f.register()
+        out.append((T, buf.getvalue()))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    assert "Good matches" in out[0][1]
