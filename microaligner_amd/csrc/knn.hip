@@ -624,37 +624,40 @@ __global__ __launch_bounds__(KH_THREADS) void kh_shortlist(const _Float16* __res
 
 // The same ranking with the QUERY operands in registers (descriptors of STEPS * 16 dimensions; DAISY's 200 -> 13 steps).
 // kh_shortlist reads both operands of every matrix instruction from LDS -- 6 KB per wave and 16 dimensions for 6 instructions --
-// and ran at a fifth of the FP16 matrix rate (1.41 ms for 22 800 x 22 900 descriptors).  Here a wave owns 64 queries for the life
-// of the block, their split operands in 2 x STEPS x 2 vector registers of 8 halves each (208 VGPRs at 13 steps; one wave per
-// SIMD, which the accumulator pairs of two independent query tiles keep busy), and only the train rows pass through LDS:
-// 64-row tiles, whole rows, double buffered; per 16 dimensions a wave reads 2 KB (ah, al) for its 6 instructions.
-// grid (tiles of 256 queries, splits of the train set); 4 waves.
-constexpr int KR_NQ = 256, KR_NT = 64, KR_THREADS = 256;
+// and ran at a fifth of the FP16 matrix rate (1.41 ms for 22 800 x 22 900 descriptors).  Here a wave owns 32 QT queries for the
+// life of the block, their split operands in QT x STEPS x 2 vector registers of 8 halves each (104 VGPRs per query tile at 13
+// steps), and only the train rows pass through LDS: 64-row tiles, whole rows, double buffered.
+//   QT = 2: 4 waves (one per SIMD), 2 KB of LDS reads (ah, al) per 6 matrix instructions;
+//   QT = 1: 8 waves (two per SIMD), 2 KB per 3 -- but the top-4 insertion of one wave's candidates (VALU: about as many cycles
+//           as the sub-tile's matrix instructions) runs under the other wave's matrix instructions.
+// grid (tiles of 256 queries, splits of the train set).
+constexpr int KR_NQ = 256, KR_NT = 64;
 
-template <int STEPS>
-__global__ __launch_bounds__(KR_THREADS) void kh_shortlist_regq(const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,
-                                                                const _Float16* __restrict__ th, const _Float16* __restrict__ tl,
-                                                                const float* __restrict__ nt2, int nq, int nt,
-                                                                int tiles_per_split, const unsigned* __restrict__ amax,
-                                                                int* __restrict__ cand_idx, float* __restrict__ cand_a4)
+template <int STEPS, int QT>
+__global__ __launch_bounds__(KR_NQ / (32 * QT) * 64) void kh_shortlist_regq(const _Float16* __restrict__ qh, const _Float16* __restrict__ ql,
+                                                                        const _Float16* __restrict__ th, const _Float16* __restrict__ tl,
+                                                                        const float* __restrict__ nt2, int nq, int nt,
+                                                                        int tiles_per_split, const unsigned* __restrict__ amax,
+                                                                        int* __restrict__ cand_idx, float* __restrict__ cand_a4)
 {
+    constexpr int THREADS = KR_NQ / (32 * QT) * 64;
     constexpr int DIMP = STEPS * 16, TP = DIMP + 8;     // row pitch in halves: 16-byte reads of 8 rows fall into distinct banks
     constexpr int SEGS = DIMP / 8;                      // 16-byte pieces per row
-    constexpr int PER = (KR_NT * SEGS + KR_THREADS - 1) / KR_THREADS;   // pieces a thread stages per operand and tile
+    constexpr int PER = (KR_NT * SEGS + THREADS - 1) / THREADS;   // pieces a thread stages per operand and tile
     extern __shared__ _Float16 hl[];
     _Float16* Th = hl;                                  // [2][KR_NT][TP]
     _Float16* Tl = Th + 2 * KR_NT * TP;
     float* Ns = reinterpret_cast<float*>(Tl + 2 * KR_NT * TP);   // [2][KR_NT]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 31, lh = lane >> 5;
-    const int q0 = blockIdx.x * KR_NQ + 64 * w, split = blockIdx.y;
+    const int q0 = blockIdx.x * KR_NQ + 32 * QT * w, split = blockIdx.y;
     const int tile0 = split * tiles_per_split, ntiles_all = (nt + KR_NT - 1) / KR_NT;
     const int ntiles = min(tiles_per_split, ntiles_all - tile0);
     const float unscale = ldexpf(-2.f, -(kh_scale_exp(amax[0]) + kh_scale_exp(amax[1])));
 
     // this lane's query operands: query q0 + 32 n + lr, dimensions 16 s + 8 lh .. + 8 (rows past the end: zeros)
-    kh_h8 bh[2][STEPS], bl[2][STEPS];
+    kh_h8 bh[QT][STEPS], bl[QT][STEPS];
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
+    for (int n = 0; n < QT; n++) {
         const int qi = q0 + 32 * n + lr;
 #pragma unroll
         for (int st = 0; st < STEPS; st++) {
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(KR_THREADS) void kh_shortlist_regq(const _Float16* 
         const int t0 = (tile0 + c) * KR_NT;
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const int e = tid + KR_THREADS * u, row = e / SEGS, sg = e - row * SEGS;
+            const int e = tid + THREADS * u, row = e / SEGS, sg = e - row * SEGS;
             sh[u] = make_uint4(0, 0, 0, 0); sl[u] = sh[u];
             if (e < KR_NT * SEGS && t0 + row < nt) {
                 sh[u] = *reinterpret_cast<const uint4*>(th + (size_t)(t0 + row) * DIMP + 8 * sg);
@@ -686,7 +689,7 @@ __global__ __launch_bounds__(KR_THREADS) void kh_shortlist_regq(const _Float16* 
     auto commit = [&](int c) {
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const int e = tid + KR_THREADS * u, row = e / SEGS, sg = e - row * SEGS;
+            const int e = tid + THREADS * u, row = e / SEGS, sg = e - row * SEGS;
             if (e < KR_NT * SEGS) {
                 *reinterpret_cast<uint4*>(Th + ((c & 1) * KR_NT + row) * TP + 8 * sg) = sh[u];
                 *reinterpret_cast<uint4*>(Tl + ((c & 1) * KR_NT + row) * TP + 8 * sg) = sl[u];
@@ -695,9 +698,9 @@ __global__ __launch_bounds__(KR_THREADS) void kh_shortlist_regq(const _Float16* 
         if (tid < KR_NT) Ns[(c & 1) * KR_NT + tid] = nstage;
     };
 
-    Top4 best[2];
+    Top4 best[QT];
 #pragma unroll
-    for (int n = 0; n < 2; n++)
+    for (int n = 0; n < QT; n++)
 #pragma unroll
         for (int e = 0; e < KM_K; e++) { best[n].d[e] = INFINITY; best[n].i[e] = 0x7fffffff; }
 
@@ -706,22 +709,24 @@ __global__ __launch_bounds__(KR_THREADS) void kh_shortlist_regq(const _Float16* 
     for (int c = 0; c < ntiles; c++) {
         if (c + 1 < ntiles) fetch(c + 1);               // in flight during this tile's arithmetic
 #pragma unroll
-        for (int sub = 0; sub < KR_NT / 32; sub++) {    // 32 train rows at a time against the wave's two query tiles
-            km_f16 acc[2];
+        for (int sub = 0; sub < KR_NT / 32; sub++) {    // 32 train rows at a time against the wave's query tiles
+            km_f16 acc[QT];
 #pragma unroll
-            for (int r = 0; r < 16; r++) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+            for (int n = 0; n < QT; n++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[n][r] = 0.f;
             const _Float16* ta = Th + ((c & 1) * KR_NT + 32 * sub + lr) * TP + 8 * lh;
             const _Float16* tb = Tl + ((c & 1) * KR_NT + 32 * sub + lr) * TP + 8 * lh;
 #pragma unroll
             for (int st = 0; st < STEPS; st++) {
                 const kh_h8 ah = *reinterpret_cast<const kh_h8*>(ta + 16 * st);
                 const kh_h8 al = *reinterpret_cast<const kh_h8*>(tb + 16 * st);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[0][st], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[1][st], acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[0][st], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[1][st], acc[1], 0, 0, 0);
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[0][st], acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[1][st], acc[1], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < QT; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[n][st], acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < QT; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[n][st], acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < QT; n++) acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[n][st], acc[n], 0, 0, 0);
             }
             // a_j = |t_j|^2 - 2 q.t_j for the 16 train rows this lane holds of either query
             const int t0 = (tile0 + c) * KR_NT + 32 * sub + 4 * lh;
@@ -731,7 +736,7 @@ __global__ __launch_bounds__(KR_THREADS) void kh_shortlist_regq(const _Float16* 
                 const int row = (r & 3) + 8 * (r >> 2);
                 const float n2 = nrm[row];
 #pragma unroll
-                for (int n = 0; n < 2; n++) {
+                for (int n = 0; n < QT; n++) {
                     const float v = __builtin_fmaf(unscale, acc[n][r], n2);
                     if (v < best[n].d[KM_K - 1]) top4_push(best[n], v, t0 + row);
                 }
@@ -745,22 +750,23 @@ __global__ __launch_bounds__(KR_THREADS) void kh_shortlist_regq(const _Float16* 
     float* cd = reinterpret_cast<float*>(Th);                  // [KR_NQ][2][KM_K]
     int* ci = reinterpret_cast<int*>(cd + KR_NQ * 2 * KM_K);
 #pragma unroll
-    for (int n = 0; n < 2; n++)
+    for (int n = 0; n < QT; n++)
 #pragma unroll
         for (int e = 0; e < KM_K; e++) {
-            const int o = ((64 * w + 32 * n + lr) * 2 + lh) * KM_K + e;
+            const int o = ((32 * QT * w + 32 * n + lr) * 2 + lh) * KM_K + e;
             cd[o] = best[n].d[e];
             ci[o] = best[n].i[e];
         }
     __syncthreads();
-    const int qq = blockIdx.x * KR_NQ + tid;
-    if (qq < nq) {
+    for (int ql_ = tid; ql_ < KR_NQ; ql_ += THREADS) {
+        const int qq = blockIdx.x * KR_NQ + ql_;
+        if (qq >= nq) continue;
         Top4 m;
 #pragma unroll
         for (int e = 0; e < KM_K; e++) { m.d[e] = INFINITY; m.i[e] = 0x7fffffff; }
         for (int e = 0; e < 2 * KM_K; e++) {
-            const float v = cd[tid * 2 * KM_K + e];
-            if (v < m.d[KM_K - 1]) top4_push(m, v, ci[tid * 2 * KM_K + e]);
+            const float v = cd[ql_ * 2 * KM_K + e];
+            if (v < m.d[KM_K - 1]) top4_push(m, v, ci[ql_ * 2 * KM_K + e]);
         }
         const size_t o = (size_t)split * nq + qq;
 #pragma unroll
@@ -881,11 +887,22 @@ extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const floa
                                (const unsigned*)(amax + 1), th, tl);
             if (regq) {
                 const size_t lds = (size_t)(4 * KR_NT * (208 + 8)) * sizeof(_Float16) + 2 * KR_NT * sizeof(float);
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kh_shortlist_regq<13>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds) != hipSuccess) { rc = MA_EHIP; break; }
-                hipLaunchKernelGGL((kh_shortlist_regq<13>), dim3(nqt_r, nsplit), dim3(KR_THREADS), lds, ctx->stream,
-                                   (const _Float16*)qh, (const _Float16*)ql, (const _Float16*)th, (const _Float16*)tl,
-                                   (const float*)nt2, nq, nt, tiles_per_split, (const unsigned*)amax, cand_idx, cand_a4);
+                static const int qt = [] { const char* e = getenv("MICROALIGNER_KNN_QT"); return e && e[0] == '2' ? 2 : 1; }();
+                hipError_t he;
+                if (qt == 2) {
+                    he = hipFuncSetAttribute(reinterpret_cast<const void*>(kh_shortlist_regq<13, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (he == hipSuccess)
+                        hipLaunchKernelGGL((kh_shortlist_regq<13, 2>), dim3(nqt_r, nsplit), dim3(256), lds, ctx->stream,
+                                           (const _Float16*)qh, (const _Float16*)ql, (const _Float16*)th, (const _Float16*)tl,
+                                           (const float*)nt2, nq, nt, tiles_per_split, (const unsigned*)amax, cand_idx, cand_a4);
+                } else {
+                    he = hipFuncSetAttribute(reinterpret_cast<const void*>(kh_shortlist_regq<13, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (he == hipSuccess)
+                        hipLaunchKernelGGL((kh_shortlist_regq<13, 1>), dim3(nqt_r, nsplit), dim3(512), lds, ctx->stream,
+                                           (const _Float16*)qh, (const _Float16*)ql, (const _Float16*)th, (const _Float16*)tl,
+                                           (const float*)nt2, nq, nt, tiles_per_split, (const unsigned*)amax, cand_idx, cand_a4);
+                }
+                if (he != hipSuccess) { rc = MA_EHIP; break; }
             } else {
                 const size_t lds = (size_t)(2 * KH_NQ * (dimh + 8) + 4 * KH_NT * KH_TP) * sizeof(_Float16) + 2 * KH_NT * sizeof(float);
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(kh_shortlist), hipFuncAttributeMaxDynamicSharedMemorySize,
