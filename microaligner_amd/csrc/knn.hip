@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
     const int tend = gridDim.y > 1 ? min(nt, tbeg + split_rows) : nt;
     const int qp = dim + 4;                  // query pitch; dim % 4 == 0 and (qp / 4) odd when dim % 8 == 0
     float* Qs = lds;                         // [KN_TQ][qp]
-    float* Ts = lds + KN_TQ * qp;            // [KN_TT][KN_TP]
+    float* Ts = lds + KN_TQ * qp;            // [2][KN_TT][KN_TP]
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int q0 = qtile * KN_TQ;
     for (int e = tid; e < KN_TQ * (dim / 4); e += 256) {
@@ -62,51 +62,74 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
 #pragma unroll
     for (int r = 0; r < 4; r++) { best[r].d0 = best[r].d1 = FLT_MAX; best[r].i0 = best[r].i1 = 0x7fffffff; }
 
-    for (int t0 = tbeg; t0 < tend; t0 += KN_TT) {
-        float acc[4][4];
+    // the train rows pass through two LDS buffers: the next chunk (64 rows x 32 dimensions) is loaded into registers before the
+    // current one is consumed and written behind it -- one barrier per chunk, no load latency between chunks (the fallback of
+    // the filtered search spent two thirds of its time there: 35 chunks of 4 us for a few dozen queries)
+    const int cpt = (dim + KN_KC - 1) / KN_KC;                       // chunks per train tile
+    const int ntile = tend > tbeg ? (tend - tbeg + KN_TT - 1) / KN_TT : 0, nchunk = ntile * cpt;
+    float4 stage[2];
+    auto fetch = [&](int c) {
+        const int t0 = tbeg + (c / cpt) * KN_TT, k0 = (c % cpt) * KN_KC;
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int u = 0; u < 2; u++) {        // 64 rows x 8 float4 = 512 float4, two per thread
+            const int e = tid + 256 * u, row = e >> 3, k4 = e & 7;
+            stage[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t0 + row < tend && k0 + 4 * k4 < dim) stage[u] = reinterpret_cast<const float4*>(t + (size_t)(t0 + row) * dim + k0)[k4];
+        }
+    };
+    auto commit = [&](int c) {
+        float* dst = Ts + (c & 1) * KN_TT * KN_TP;
 #pragma unroll
-            for (int c = 0; c < 4; c++) acc[r][c] = 0.f;
-        for (int k0 = 0; k0 < dim; k0 += KN_KC) {
-            __syncthreads();                 // previous chunk consumed (first pass: Qs complete)
+        for (int u = 0; u < 2; u++) {
+            const int e = tid + 256 * u, row = e >> 3, k4 = e & 7;
+            *reinterpret_cast<float4*>(dst + row * KN_TP + 4 * k4) = stage[u];
+        }
+    };
+    if (nchunk > 0) { fetch(0); commit(0); }
+    __syncthreads();                         // Qs and the first chunk complete
+    float acc[4][4];
+    for (int c = 0; c < nchunk; c++) {
+        const int t0 = tbeg + (c / cpt) * KN_TT, kcix = c % cpt, k0 = kcix * KN_KC;
+        if (c + 1 < nchunk) fetch(c + 1);
+        if (kcix == 0) {
 #pragma unroll
-            for (int u = 0; u < 2; u++) {    // 64 rows x 8 float4 = 512 float4, two per thread
-                const int e = tid + 256 * u, row = e >> 3, k4 = e & 7;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t0 + row < tend && k0 + 4 * k4 < dim) v = reinterpret_cast<const float4*>(t + (size_t)(t0 + row) * dim + k0)[k4];
-                *reinterpret_cast<float4*>(Ts + row * KN_TP + 4 * k4) = v;
-            }
-            __syncthreads();
-            const int kc = min(KN_KC, dim - k0) / 4;
-            for (int k4 = 0; k4 < kc; k4++) {
-                float4 qv[4], tv[4];
+            for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) qv[r] = *reinterpret_cast<const float4*>(Qs + (ty * 4 + r) * qp + k0 + 4 * k4);
+                for (int cc = 0; cc < 4; cc++) acc[r][cc] = 0.f;
+        }
+        const float* Tc = Ts + (c & 1) * KN_TT * KN_TP;
+        const int kc = min(KN_KC, dim - k0) / 4;
+        for (int k4 = 0; k4 < kc; k4++) {
+            float4 qv[4], tv[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) tv[c] = *reinterpret_cast<const float4*>(Ts + (tx + 16 * c) * KN_TP + 4 * k4);
+            for (int r = 0; r < 4; r++) qv[r] = *reinterpret_cast<const float4*>(Qs + (ty * 4 + r) * qp + k0 + 4 * k4);
 #pragma unroll
-                for (int r = 0; r < 4; r++)
+            for (int cc = 0; cc < 4; cc++) tv[cc] = *reinterpret_cast<const float4*>(Tc + (tx + 16 * cc) * KN_TP + 4 * k4);
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        // d2 = d2 + d*d, product and sum rounded separately (the file is built with -ffp-contract=off):
-                        // the definition sparse_cpu.knn2_sequential restates with numpy, bit for bit
-                        float d;
-                        d = qv[r].x - tv[c].x; acc[r][c] = acc[r][c] + d * d;
-                        d = qv[r].y - tv[c].y; acc[r][c] = acc[r][c] + d * d;
-                        d = qv[r].z - tv[c].z; acc[r][c] = acc[r][c] + d * d;
-                        d = qv[r].w - tv[c].w; acc[r][c] = acc[r][c] + d * d;
-                    }
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int cc = 0; cc < 4; cc++) {
+                    // d2 = d2 + d*d, product and sum rounded separately (the file is built with -ffp-contract=off):
+                    // the definition sparse_cpu.knn2_sequential restates with numpy, bit for bit
+                    float d;
+                    d = qv[r].x - tv[cc].x; acc[r][cc] = acc[r][cc] + d * d;
+                    d = qv[r].y - tv[cc].y; acc[r][cc] = acc[r][cc] + d * d;
+                    d = qv[r].z - tv[cc].z; acc[r][cc] = acc[r][cc] + d * d;
+                    d = qv[r].w - tv[cc].w; acc[r][cc] = acc[r][cc] + d * d;
+                }
+        }
+        if (kcix == cpt - 1) {
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                const int j = t0 + tx + 16 * cc;
+                if (j < tend) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) top2_push(best[r], acc[r][cc], j);
+                }
             }
         }
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const int j = t0 + tx + 16 * c;
-            if (j < tend) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) top2_push(best[r], acc[r][c], j);
-            }
-        }
+        if (c + 1 < nchunk) commit(c + 1);
+        __syncthreads();
     }
     // merge the 16 partial results of every query row (Qs is free now)
     __syncthreads();
@@ -783,7 +806,7 @@ __global__ __launch_bounds__(KR_NQ / (32 * QT) * 64) void kh_shortlist_regq(cons
 static int knn2_exact(ma_ctx* ctx, const float* query, int nq, const float* train, int nt, int dim, int* idx_out,
                       float* dist_out, const int* qlist, const int* qcount, int nsplit, float4* part)
 {
-    size_t lds = (size_t)(KN_TQ * (dim + 4) + KN_TT * KN_TP) * sizeof(float);
+    size_t lds = (size_t)(KN_TQ * (dim + 4) + 2 * KN_TT * KN_TP) * sizeof(float);
     lds = std::max(lds, (size_t)KN_TQ * 16 * 4 * sizeof(float));   // the final merge reuses the buffer
     MA_REQUIRE(lds <= 160 * 1024, "descriptor length out of range");
     if (lds > 64 * 1024)
@@ -851,7 +874,10 @@ extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const floa
     int sc = 4;
     while (sc < nsplit * KM_K) sc *= 2;
 
-    const int fsplit = std::max(1, std::min(64, nt / 256));      // train ranges of the exact fallback
+    // train ranges of the exact fallback.  A block works through a 64-query tile whatever the number of real queries in it, so
+    // the few uncertified queries (one to six tiles) are spread over the chip by cutting the train set finely: one 64-row tile
+    // per range where the partial results (16 bytes per query and range) stay within 256 MB
+    const int fsplit = (int)std::max<size_t>(1, std::min<size_t>({(size_t)256, (size_t)nt / 64, ((size_t)256 << 20) / ((size_t)nq * 16)}));
     const size_t b_nt2 = ma_align_up((size_t)nt * 4, 256), b_ci = ma_align_up((size_t)nsplit * nq * KM_K * 4, 256),
                  b_a4 = ma_align_up((size_t)nsplit * nq * 4, 256), b_ql = ma_align_up((size_t)nq * 4, 256),
                  b_part = fsplit > 1 ? (size_t)fsplit * nq * sizeof(float4) : 0;
