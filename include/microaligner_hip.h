@@ -403,7 +403,8 @@ int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const float* train, i
  * (squared) distances ma_knn2_l2 left on the device, then the counterpart of cv.estimateAffinePartial2D(query points -> train
  * points, RANSAC, confidence) -- bit for bit microaligner_amd/feature_reg/sparse_cpu.py:estimate_affine_partial_2d, whose
  * random sequence numpy's Generator(PCG64(seed)) defines: rng_state = {state hi, state lo, inc hi, inc lo} of
- * numpy.random.PCG64(seed).state.  idx / dist_sq: (nq, 2) device arrays; query_pts / train_pts: (n, 2) float64 (x, y) device
+ * numpy.random.PCG64(seed).state; NULL: the state of seed 0, the reference-side default (a C host needs no numpy).
+ * idx / dist_sq: (nq, 2) device arrays; query_pts / train_pts: (n, 2) float64 (x, y) device
  * arrays.  Results on the host: the 2 x 3 matrix (row major), the number of good matches and
  * status 0 = matrix valid, 1 = fewer than 3 good matches (the reference returns the identity), 2 = no model (cv2 returns
  * None), 3 = coordinates not integer-valued or too large for exact sums: not computed, use the host statement. */

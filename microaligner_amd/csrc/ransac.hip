@@ -338,7 +338,10 @@ extern "C" {
 
 int ma_host_pcg64_choice2(const unsigned long long state[4], int n, int count, int* pairs_out)
 {
-    MA_REQUIRE(state && pairs_out && n >= 2 && count >= 0, "bad arguments");
+    static const unsigned long long seed0[4] = {0x1aa1b5345996452dULL, 0x09585eb7a69561e3ULL, 0x418ddadb3af71a82ULL,
+                                                0x588133bc447873a9ULL};   // numpy.random.PCG64(0)
+    if (!state) state = seed0;
+    MA_REQUIRE(pairs_out && n >= 2 && count >= 0, "bad arguments");
     Pcg64 g;
     g.state = ((u128)state[0] << 64) | state[1];
     g.inc = ((u128)state[2] << 64) | state[3];
@@ -358,8 +361,12 @@ int ma_match_similarity(ma_ctx* ctx, const int* idx, const float* dist_sq, int n
                         int max_iters, const unsigned long long rng_state[4], double* m2x3_host, int* n_good_host,
                         int* status_host)
 {
-    MA_REQUIRE(ctx && idx && dist_sq && query_pts && train_pts && rng_state && m2x3_host && n_good_host && status_host,
-               "NULL argument");
+    MA_REQUIRE(ctx && idx && dist_sq && query_pts && train_pts && m2x3_host && n_good_host && status_host, "NULL argument");
+    // rng_state == NULL: the state of numpy.random.PCG64(0) -- the seed the host statement defaults to -- so that a C host needs
+    // no numpy to make the call (tests/test_feature_reg.py compares the constants with numpy's)
+    static const unsigned long long seed0[4] = {0x1aa1b5345996452dULL, 0x09585eb7a69561e3ULL, 0x418ddadb3af71a82ULL,
+                                                0x588133bc447873a9ULL};
+    if (!rng_state) rng_state = seed0;
     MA_REQUIRE(nq >= 1 && nt >= 1 && max_iters >= 1 && max_iters <= 1000000, "bad sizes");
     MA_REQUIRE(confidence > 0.0 && confidence < 1.0 && reproj_threshold > 0.0, "bad RANSAC parameters");
     MA_HIP(hipSetDevice(ctx->device));

@@ -535,6 +535,11 @@ def test_random_stream_of_the_device_ransac_is_numpys():
             L.check(lib.ma_host_pcg64_choice2(st, n, cnt, out.ctypes.data_as(C.POINTER(C.c_int))))
             rng = np.random.default_rng(seed)
             assert np.array_equal(out, np.array([rng.choice(n, 2, replace=False) for _ in range(cnt)])), (seed, n)
+    # a NULL state means numpy.random.PCG64(0): the constants in csrc/ransac.hip are numpy's
+    out = np.zeros((500, 2), np.int32)
+    L.check(lib.ma_host_pcg64_choice2(None, 12345, 500, out.ctypes.data_as(C.POINTER(C.c_int))))
+    rng0 = np.random.default_rng(0)
+    assert np.array_equal(out, np.array([rng0.choice(12345, 2, replace=False) for _ in range(500)]))
     rng = np.random.default_rng(3)
     for _ in range(3000):
         n = int(rng.integers(2, 50000))
