@@ -529,23 +529,35 @@ __global__ __launch_bounds__(KC_T) void kp_collect_kernel(const int* __restrict_
         if (take[e]) k[pos++] = ((unsigned long long)(65535 - v[e]) << 32) | (unsigned)(i0 + e);
 }
 
-// C. bitonic sort of the tile's <= 8192 keys in LDS: ascending key = descending score, row-major among equals
+// C. bitonic sort of the tile's <= 8192 keys in LDS: ascending key = descending score, row-major among equals.  kp_collect
+//    leaves the list in row-major order (chunk by chunk, thread by thread, element by element), so the POSITION in the list
+//    stands for the index: the sort runs on 32-bit words (255 - score) << 13 | position (half the LDS traffic of the 64-bit
+//    keys) and the sorted positions pick index and score from the list.
 __global__ __launch_bounds__(KS_T) void kp_sort_kernel(const unsigned long long* __restrict__ keys_in, const int* __restrict__ cut,
                                                        int Pi, int limit, int* __restrict__ kp_out, int* __restrict__ counts)
 {
-    __shared__ unsigned long long keys[KS_CAP];
+    static_assert(KS_CAP <= (1 << 13), "positions take 13 bits");
+    __shared__ unsigned keys[KS_CAP];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int n_sel = cut[t * 3 + 2];
+    const unsigned long long* list = keys_in + (size_t)t * KS_CAP;
     int m = 1;
     while (m < n_sel) m <<= 1;
-    for (int i = tid; i < m; i += KS_T) keys[i] = i < n_sel ? keys_in[(size_t)t * KS_CAP + i] : ~0ull;
+    for (int i = tid; i < m; i += KS_T) {
+        unsigned k = 0xffffffffu;
+        if (i < n_sel) {
+            const unsigned inv_score = (unsigned)(list[i] >> 32);          // 65535 - score, score in 1 .. 254
+            k = ((inv_score - (65535u - 255u)) << 13) | (unsigned)i;
+        }
+        keys[i] = k;
+    }
     __syncthreads();
     for (int k = 2; k <= m; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < m; i += KS_T) {
                 const int l = i ^ j;
                 if (l > i) {
-                    const unsigned long long a = keys[i], b = keys[l];
+                    const unsigned a = keys[i], b = keys[l];
                     const bool up = (i & k) == 0;
                     if ((a > b) == up) { keys[i] = b; keys[l] = a; }
                 }
@@ -554,14 +566,13 @@ __global__ __launch_bounds__(KS_T) void kp_sort_kernel(const unsigned long long*
         }
     }
     for (int i = tid; i < n_sel; i += KS_T) {
-        const unsigned long long key = keys[i];
+        const unsigned long long key = list[keys[i] & 0x1fffu];
         const int idx = (int)(key & 0xffffffffu), sc = 65535 - (int)(key >> 32);
         int* o = kp_out + ((size_t)t * limit + i) * 3;
         o[0] = idx % Pi; o[1] = idx / Pi; o[2] = sc;
     }
     if (tid == 0) counts[t] = n_sel;
 }
-
 
 // ---- the selection's keypoints, compacted on the device (combine_features' layout, tile_registration.py:37-74) --------------
 // base[t] = number of keypoints of the batch's tiles before t that stay (tiles with fewer than three are dropped,
