@@ -758,3 +758,47 @@ def test_feature_registrator_device_path_equals_the_host_statement(seed):
         out.append((T, buf.getvalue()))
     assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
     assert "Good matches" in out[0][1]
+
+
+@pytest.mark.gpu
+def test_a_plain_c_host_drives_a_matching_round(ctx, tmp_path):
+    """tests/c_host/feature_host.c: a C program that knows only include/microaligner_hip.h (gcc, linked against
+    libmicroaligner_hip.so) extracts the features of two images, searches the two nearest neighbours and fits the similarity --
+    ma_feature_extract, ma_knn2_l2, ma_match_similarity with the built-in seed-0 random state -- and prints what the Python path
+    (find_features_of_device_image, Context.knn2, Context.match_similarity) computes: the same counts, the same matrix."""
+    import os
+    import subprocess
+    from microaligner_amd import _lib
+    from microaligner_amd.feature_reg import feature_detection as FD
+    from microaligner_amd.feature_reg.sparse_cpu import Daisy
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "feature_host"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_host", "feature_host.c"), "-o", str(exe), "-L", libdir,
+                    "-lmicroaligner_hip", f"-Wl,-rpath,{libdir}"], check=True, capture_output=True, text=True)
+    H, W, tile = 700, 820, 300
+    ref = synthetic.make_cells(H, W, seed=21)
+    th = np.deg2rad(0.4)
+    mov = O.warp_affine(ref, np.array([[np.cos(th), -np.sin(th), 6.0], [np.sin(th), np.cos(th), -4.0]]))
+    dref, dmov = O.dog(ref, True), O.dog(mov, True)
+    dref.tofile(tmp_path / "ref.bin")
+    dmov.tofile(tmp_path / "mov.bin")
+    halves, cos_sin, offsets = FD._daisy_tables(Daisy(radius=21, q_radius=3, q_theta=8, q_hist=8))
+    with open(tmp_path / "tables.bin", "wb") as f:
+        f.write(np.array([len(h) - 1 for h in halves], np.int32).tobytes())
+        for h in halves:
+            f.write(np.ascontiguousarray(h, np.float64).tobytes())
+        f.write(np.ascontiguousarray(cos_sin, np.float64).tobytes())
+        f.write(np.ascontiguousarray(offsets, np.float64).tobytes())
+    r = subprocess.run([str(exe), str(H), str(W), str(tile), str(tmp_path / "ref.bin"), str(tmp_path / "mov.bin"),
+                        str(tmp_path / "tables.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = r.stdout.split()
+    fr = FD.find_features_of_device_image(ctx.asdevice(dref), tile, ctx)
+    fm = FD.find_features_of_device_image(ctx.asdevice(dmov), tile, ctx)
+    idx_d, dist_d = ctx.knn2(fm.descriptors_for_search, fr.descriptors_for_search, on_device=True)
+    mat, n_good, status = ctx.match_similarity(idx_d, dist_d, fm.device_pts(ctx), fr.device_pts(ctx))
+    assert [int(v) for v in got[:4]] == [len(fr.descriptors_for_search), len(fm.descriptors_for_search), n_good, status]
+    assert status == 0 and n_good > 100
+    assert np.array_equal(np.array([float(v) for v in got[4:]]).reshape(2, 3), mat)
