@@ -416,6 +416,32 @@ int ma_match_similarity(ma_ctx* ctx, const int* idx, const float* dist_sq, int n
  * given PCG64 state (pairs_out: count x 2), and the adaptive iteration count of the RANSAC loop. */
 int ma_host_pcg64_choice2(const unsigned long long state[4], int n, int count, int* pairs_out);
 int ma_host_ransac_iterations(int count, int n, double confidence, int max_iters, int it, int* iters);
+/* One round of FeatureRegistrator's level loop (feature_reg/feature_registrator.py:162-207) in one call: features of the
+ * current moving image (ma_feature_extract on dog(current) -- or on the uint8 image itself without use_dog), 2-NN, ratio test
+ * and RANSAC against the level's reference features (ma_knn2_l2, ma_match_similarity, seed 0), candidate =
+ * cv2.warpAffine(current, estimate) (ma_warp_affine_cv), dog(candidate), and both halves of the mutual-information gate
+ * (NMI(ref_gate, dog(candidate)), NMI(ref_gate, dog(current)), chunks of nmi_chunk elements, 0 = whole image).  Everything
+ * stays on the device; the result struct and the chunk scores are all that comes back (the call synchronises).
+ * current: (H, W) device image; current_gate: dog(current) if the caller has it, else NULL and it is written to
+ * current_gate_out; ref_gate: dog(reference level); ref_desc / ref_pts / n_ref: the reference features as ma_feature_extract
+ * left them; tables as for ma_daisy_describe.  candidate_out (H, W, dtype) and candidate_gate_out (H, W uint8) are written
+ * unless the estimate is the identity (then the "after" scores compare the current image with itself, as the reference's
+ * loop does).  status: ma_match_similarity's (0 matrix valid, 1 fewer than 3 good matches, 2 no model, 3 not computed: use the
+ * host statement -- nothing after the matching has run then) or 4 = the current image has no features or the reference fewer
+ * than two (the reference loop takes the identity without a "Good matches" line).  zero_max: bit 0 = dog(current) met an image
+ * whose max() is 0, bit 1 = dog(candidate) did -- the reference's dog() returns such an image unchanged (:288-291); the caller
+ * repeats the level with the step-by-step entry points. */
+typedef struct ma_feature_round_result {
+    double m2x3[6];
+    int n_query, n_good, status, is_identity, n_scores, zero_max;
+} ma_feature_round_result;
+int ma_feature_round(ma_ctx* ctx, const void* current, int dtype, int H, int W, const uint8_t* current_gate,
+                     uint8_t* current_gate_out, const uint8_t* ref_gate, const float* ref_desc, const double* ref_pts,
+                     int n_ref, int tile, int use_dog, size_t nmi_chunk, const double* const* weights_host, const int* radii,
+                     const double* cos_sin_host, const double* offs_host, size_t workspace_bytes, void* candidate_out,
+                     uint8_t* candidate_gate_out, double* scores_after_host, double* scores_before_host, int max_scores,
+                     ma_feature_round_result* res);
+
 /* ---- dense halves of the feature stage (FeatureRegistrator), batched over nt square tiles of side P ----
  * ma_fast_nms: FAST-9/16 corner score of the tile interiors (tile[margin:-margin, margin:-margin], as
  * feature_detection.py:105 cuts them) kept only at strict 3x3 local maxima -- the pixels

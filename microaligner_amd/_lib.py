@@ -102,7 +102,16 @@ class MaLevelReport(C.Structure):
     _fields_ = [("factor", _i), ("h", _i), ("w", _i), ("mi_after", _d), ("mi_before", _d), ("accepted", _i)]
 
 
+class MaFeatureRoundResult(C.Structure):
+    """ma_feature_round_result of include/microaligner_hip.h."""
+    _fields_ = [("m2x3", _d * 6), ("n_query", _i), ("n_good", _i), ("status", _i), ("is_identity", _i), ("n_scores", _i),
+                ("zero_max", _i)]
+
+
 SIGNATURES.update({
+    "ma_feature_round": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _sz, C.POINTER(C.POINTER(_d)),
+                              C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), _sz, _vp, _vp, C.POINTER(_d), C.POINTER(_d), _i,
+                              C.POINTER(MaFeatureRoundResult)]),
     "ma_ctx_trim": (_i, [_vp]),
     "ma_ctx_transfer_stats": (_i, [_vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), _i]),
     "ma_params_default": (None, [C.POINTER(MaParams)]),

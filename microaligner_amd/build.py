@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmicroaligner_hip.so")
-SOURCES = ["ma_api.hip", "farneback.hip", "remap.hip", "pyramid.hip", "dog.hip", "nmi.hip", "affine.hip", "knn.hip", "daisy.hip", "ransac.hip", "register.hip", "probe.hip"]
+SOURCES = ["ma_api.hip", "farneback.hip", "remap.hip", "pyramid.hip", "dog.hip", "nmi.hip", "affine.hip", "knn.hip", "daisy.hip", "ransac.hip", "feature_round.hip", "register.hip", "probe.hip"]
 HEADERS = [os.path.join(CSRC, "ma_internal.h"), os.path.join(HERE, "..", "include", "microaligner_hip.h")]
 # -fno-slp-vectorize: the SLP vectoriser packs the sliding-window blur into v_pk_* ops with a storm of
 # register-pair shuffles (measured 1.65x slower on blur_h_solve, profiles/r01_*); packed math is written by hand
@@ -52,7 +52,7 @@ def source_hash():
     # the streams behave: both are part of what a profile measures.  Left out: the clock probe and the feature stage
     # (FAST / DAISY / 2-NN / affine warp), which has its own tests and timings and no kernel on the measured path (cfg3:
     # pyramid, DOG, Farneback, warp, merge, NMI)
-    off_path = {"probe.hip", "knn.hip", "daisy.hip", "ransac.hip", "affine.hip"}
+    off_path = {"probe.hip", "knn.hip", "daisy.hip", "ransac.hip", "feature_round.hip", "affine.hip"}
     for path in [os.path.join(CSRC, s) for s in SOURCES if s not in off_path] + HEADERS:
         h.update(open(path, "rb").read())
     h.update(" ".join(_flags()).encode())

@@ -86,6 +86,9 @@ struct ma_ctx {
     // NULL outside ma_optflow_register
     int* dog_sticky = nullptr;
     int* dog_sticky_buf = nullptr;   // the allocation behind it (owned by the ctx)
+    // two page-locked ints for the max() == 0 reports of the dog() calls inside ma_feature_round (written in stream order,
+    // read after the round's synchronisation); allocated on first use, owned by the ctx
+    int* round_flags = nullptr;
     // companion ctx (own stream and workspace, same device) for the work of ma_optflow_register that does not depend on
     // the flow -- dog(ref) and dog(mov) of every level -- and the events that order the two streams; created on first use
     ma_ctx* side = nullptr;

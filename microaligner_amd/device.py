@@ -919,6 +919,41 @@ class Context:
         desc.shape = (n.value, 200)
         return desc, pts, resp, n.value
 
+    def feature_round(self, current, current_gate, ref_gate, ref_features, tile, use_dog, nmi_chunk, weights, cos_sin, offsets,
+                      workspace_bytes=0):
+        """One round of FeatureRegistrator's level loop in one call (ma_feature_round).  current: the level's moving image
+        (DeviceArray); current_gate: dog(current) or None (then it is computed and returned); ref_gate: dog(reference level);
+        ref_features: (descriptors DeviceArray (n, 200), points raw buffer, n) of the reference level or None.  Returns a dict:
+        estimate (2, 3), n_query, n_good, status, is_identity, zero_max, scores_after, scores_before (per chunk), current_gate,
+        candidate, candidate_gate (the last two None for an identity estimate)."""
+        H, W = current.shape
+        made_gate = current_gate is None
+        gate_out = self.empty((H, W), np.uint8) if made_gate else None
+        cand, cand_gate = self.empty((H, W), current.dtype), self.empty((H, W), np.uint8)
+        n = H * W
+        nch = 1 if (nmi_chunk <= 0 or nmi_chunk >= n) else (n + nmi_chunk - 1) // nmi_chunk
+        s_after, s_before = (C.c_double * nch)(), (C.c_double * nch)()
+        halves = [np.ascontiguousarray(w, np.float64) for w in weights]
+        wptr = (C.POINTER(C.c_double) * 3)(*[h.ctypes.data_as(C.POINTER(C.c_double)) for h in halves])
+        radii = (C.c_int * 3)(*[len(h) - 1 for h in halves])
+        cs = np.ascontiguousarray(cos_sin, np.float64)
+        of = np.ascontiguousarray(offsets, np.float64)
+        res = L.MaFeatureRoundResult()
+        rdesc, rpts, rn = ref_features if ref_features is not None else (None, None, 0)
+        self._run(self.lib.ma_feature_round, current.ptr, _dt(current.dtype), H, W,
+                  None if made_gate else current_gate.ptr, gate_out.ptr if made_gate else None, ref_gate.ptr,
+                  rdesc.ptr if rn else None, rpts.ptr if rn else None, int(rn), int(tile), 1 if use_dog else 0,
+                  int(max(nmi_chunk, 0)), wptr, radii, cs.ctypes.data_as(C.POINTER(C.c_double)),
+                  of.ctypes.data_as(C.POINTER(C.c_double)), int(workspace_bytes), cand.ptr, cand_gate.ptr, s_after, s_before, nch,
+                  C.byref(res))
+        ident = bool(res.is_identity)
+        return dict(estimate=np.array(list(res.m2x3), np.float64).reshape(2, 3), n_query=res.n_query, n_good=res.n_good,
+                    status=res.status, is_identity=ident, zero_max=res.zero_max,
+                    scores_after=np.frombuffer(s_after, np.float64, res.n_scores).copy(),
+                    scores_before=np.frombuffer(s_before, np.float64, res.n_scores).copy(),
+                    current_gate=gate_out if made_gate else current_gate,
+                    candidate=None if ident else cand, candidate_gate=None if ident else cand_gate)
+
     def download_raw(self, buf, shape, dtype):
         """A raw device buffer (_raw) as a host array of the given shape and dtype."""
         out = np.empty(shape, dtype)

@@ -220,21 +220,25 @@ class FeatureRegistrator:
         current_gate = None
         for it in range(self.num_iterations):
             self._log("    Iteration", it + 1, "/", self.num_iterations)
-            if current_gate is None:
-                current_gate = self.dog(current, True)
-            # the exact 2-NN search over up to 45 000 x 45 000 descriptors, the ratio test and the RANSAC fit run on the device
-            # (ma_knn2_l2, ma_match_similarity): the matrix and the match count come back
-            mov_features = self._features_of(current, pre=current_gate if self.use_dog else None)
-            if self.features_on_host:
-                from .sparse_cpu import knn2_sequential
-                estimate = register_img_pair(ref_level.features, mov_features, self.verbose, knn=knn2_sequential, log=self._log)
+            fused = self._fused_round(ctx, ref_level, ref_gate, current, current_gate)
+            if fused is not None:
+                estimate, is_identity, candidate, candidate_gate, current_gate, improved = fused
             else:
-                estimate = register_img_pair(ref_level.features, mov_features, self.verbose, log=self._log, ctx=ctx)
-            is_identity = bool(np.array_equal(estimate, affine_math.IDENTITY))
-            candidate = current if is_identity else self.transform_img(current, estimate)
-            candidate_gate = current_gate if is_identity else self.dog(candidate, True)
-            improved = check_if_higher_similarity(ref_gate, candidate_gate, current_gate,
-                                                  self.tile_size, self.verbose, log=self._log)
+                if current_gate is None:
+                    current_gate = self.dog(current, True)
+                # the exact 2-NN search over up to 45 000 x 45 000 descriptors, the ratio test and the RANSAC fit run on the
+                # device (ma_knn2_l2, ma_match_similarity): the matrix and the match count come back
+                mov_features = self._features_of(current, pre=current_gate if self.use_dog else None)
+                if self.features_on_host:
+                    from .sparse_cpu import knn2_sequential
+                    estimate = register_img_pair(ref_level.features, mov_features, self.verbose, knn=knn2_sequential, log=self._log)
+                else:
+                    estimate = register_img_pair(ref_level.features, mov_features, self.verbose, log=self._log, ctx=ctx)
+                is_identity = bool(np.array_equal(estimate, affine_math.IDENTITY))
+                candidate = current if is_identity else self.transform_img(current, estimate)
+                candidate_gate = current_gate if is_identity else self.dog(candidate, True)
+                improved = check_if_higher_similarity(ref_gate, candidate_gate, current_gate,
+                                                      self.tile_size, self.verbose, log=self._log)
             plausible = (affine_math.centre_stays_inside(estimate, mov_level.shape)
                          and affine_math.scales_plausible(estimate))
             self._check_deferred()       # the gate has just synchronised: the flags of this round's dog() calls are in
@@ -249,6 +253,41 @@ class FeatureRegistrator:
                 self._log("    Worse alignment than before")
                 rounds.append(affine_math.IDENTITY.copy())
         return affine_math.compose(rounds)
+
+    def _fused_round(self, ctx, ref_level, ref_gate, current, current_gate):
+        """The round's device work in ONE call (ma_feature_round: dog(current) if missing, features, 2-NN, ratio test, RANSAC,
+        cv2.warpAffine, dog(candidate), both halves of the gate) where the step-by-step path would make the very same calls:
+        the fast attempt of register(), device images, uint8 feature images, sides up to 32000 px (cv2.warpAffine's range).
+        Returns None when the round has to go step by step, else (estimate, is_identity, candidate, candidate_gate,
+        current_gate, improved) -- the same values and the same log lines."""
+        from ..shared_modules.tiling import is_tiled
+        from .feature_detection import DEVICE_WORKSPACE_BYTES, _daisy_tables
+        from .sparse_cpu import Daisy
+        ref_f = ref_level.features
+        if not (self._fast and not self.features_on_host and isinstance(current, DeviceArray) and current.ndim == 2
+                and isinstance(ref_gate, DeviceArray) and ref_gate.dtype == np.uint8 and ref_gate.shape == current.shape
+                and max(current.shape) <= 32000 and (self.use_dog or current.dtype == np.uint8)
+                and (current_gate is None or (isinstance(current_gate, DeviceArray) and current_gate.dtype == np.uint8))
+                and (not ref_f.is_valid() or (ref_f._dev is not None and isinstance(ref_f.descriptors_for_search, DeviceArray)))):
+            return None
+        halves, cos_sin, offsets = _daisy_tables(Daisy(radius=21, q_radius=3, q_theta=8, q_hist=8))
+        chunk = self.tile_size * self.tile_size if is_tiled(current.shape, self.tile_size) else 0
+        ref_features = (ref_f.descriptors_for_search, ref_f._dev[1], ref_f._dev[3]) if ref_f.is_valid() else None
+        r = ctx.feature_round(current, current_gate, ref_gate, ref_features, self.tile_size, self.use_dog, chunk, halves, cos_sin,
+                              offsets, workspace_bytes=DEVICE_WORKSPACE_BYTES)
+        if r["zero_max"]:
+            raise _ZeroMaxImage()
+        if r["status"] == 3:        # (integer keypoints never get here) -- the host statement decides, step by step
+            return None
+        if r["status"] != 4:
+            self._log("    Good matches", r["n_good"], "/", r["n_query"])
+        after, before = ((float(r["scores_after"][0]), float(r["scores_before"][0])) if chunk == 0 else
+                         (np.mean(r["scores_after"]), np.mean(r["scores_before"])))
+        self._log("    MI score after:", after, "| MI score before:", before)
+        ident = r["is_identity"]
+        gate = r["current_gate"]
+        return (r["estimate"], ident, current if ident else r["candidate"], gate if ident else r["candidate_gate"], gate,
+                [after > before])
 
     def get_dog_sigmas(self, pyr_factor: int) -> Tuple[int, int]:
         if pyr_factor > 16:

@@ -42,7 +42,8 @@ def test_constants_of_the_header_match_the_bindings():
     for name, kid in _lib.KERNEL_IDS.items():
         assert vals["MA_K_" + name.upper()] == kid
     # struct layouts: field names and order of ma_params / ma_level_report
-    for cname, cls in (("ma_params", _lib.MaParams), ("ma_level_report", _lib.MaLevelReport)):
+    for cname, cls in (("ma_params", _lib.MaParams), ("ma_level_report", _lib.MaLevelReport),
+                       ("ma_feature_round_result", _lib.MaFeatureRoundResult)):
         body = re.search(r"typedef struct " + cname + r" \{(.*?)\} " + cname + ";", text, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []
@@ -51,9 +52,11 @@ def test_constants_of_the_header_match_the_bindings():
             if decl:
                 ctype, names = decl.split(None, 1)
                 fields += [(n.strip(), ctype) for n in names.split(",")]
-        assert [f[0] for f in cls._fields_] == [f[0] for f in fields], cname
-        for (_, ct), (_, decl_t) in zip(cls._fields_, fields):
-            assert {"int": C.c_int, "double": C.c_double}[decl_t] is ct
+        assert [f[0] for f in cls._fields_] == [re.sub(r"\[\d+\]", "", f[0]) for f in fields], cname
+        for (_, ct), (name, decl_t) in zip(cls._fields_, fields):
+            base = {"int": C.c_int, "double": C.c_double}[decl_t]
+            dim = re.search(r"\[(\d+)\]", name)
+            assert (ct is base) if not dim else (ct._type_ is base and ct._length_ == int(dim.group(1)))
 
 
 def test_numpy_mean_replica_is_bit_identical():
