@@ -46,6 +46,7 @@ class FeatureRegistrator:
         self.verbose = True      # addition: the reference prints unconditionally
         self.compat_mov_getter = True   # the mov_img getter returns the REFERENCE image, as the reference's does; False: the moving image
         self._levels: List[_Level] = []   # reference side, coarsest first; kept for register(reuse_ref_img=True)
+        self.fuse_rounds = True           # a round's device work in one C call (ma_feature_round) where that makes the same calls
         self.features_on_host = False     # True: features and matching by the HOST statement (sparse_cpu.py, the definition the
         #                                     kernels reproduce; slow) -- dense steps stay on the device.  For cross-checks
         self._careful = False             # True: register() runs in the careful mode only (see register())
@@ -264,7 +265,7 @@ class FeatureRegistrator:
         from .feature_detection import DEVICE_WORKSPACE_BYTES, _daisy_tables
         from .sparse_cpu import Daisy
         ref_f = ref_level.features
-        if not (self._fast and not self.features_on_host and isinstance(current, DeviceArray) and current.ndim == 2
+        if not (self._fast and self.fuse_rounds and not self.features_on_host and isinstance(current, DeviceArray) and current.ndim == 2
                 and isinstance(ref_gate, DeviceArray) and ref_gate.dtype == np.uint8 and ref_gate.shape == current.shape
                 and max(current.shape) <= 32000 and (self.use_dog or current.dtype == np.uint8)
                 and (current_gate is None or (isinstance(current_gate, DeviceArray) and current_gate.dtype == np.uint8))

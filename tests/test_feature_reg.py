@@ -802,3 +802,30 @@ def test_a_plain_c_host_drives_a_matching_round(ctx, tmp_path):
     assert [int(v) for v in got[:4]] == [len(fr.descriptors_for_search), len(fm.descriptors_for_search), n_good, status]
     assert status == 0 and n_good > 100
     assert np.array_equal(np.array([float(v) for v in got[4:]]).reshape(2, 3), mat)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_dog,dtype", [(True, np.uint16), (False, np.uint8), (True, np.float32)])
+def test_fused_round_equals_the_step_by_step_entry_points(use_dog, dtype):
+    """ma_feature_round chains the calls the level loop otherwise makes one by one: the same matrix and the same log with
+    `fuse_rounds` on and off, with and without the DOG preprocess, for an accepted and for a rejected pair."""
+    import contextlib
+    import io
+    from microaligner_amd import FeatureRegistrator
+    H, W = 640, 700
+    ref = synthetic.make_cells(H, W, seed=33, dtype=dtype)
+    th = np.deg2rad(-0.5)
+    pairs = [O.warp_affine(ref, np.array([[np.cos(th), -np.sin(th), -8.0], [np.sin(th), np.cos(th), 5.0]])),
+             synthetic.make_cells(H, W, seed=1033, dtype=dtype)]
+    for mov in pairs:
+        out = []
+        for fuse in (True, False):
+            f = FeatureRegistrator()
+            f.num_pyr_lvl, f.num_iterations, f.tile_size, f.use_dog, f.use_full_res_img = 1, 3, 300, use_dog, True
+            f.fuse_rounds = fuse
+            f.ref_img, f.mov_img = ref, mov
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                T = f.register()
+            out.append((T, buf.getvalue()))
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
