@@ -511,6 +511,42 @@ def host_stream_leg(n_pairs, ref, mov, params, dtype):
 HOST_MODES = ("stream_pairs_pageable", "stream_pairs_page_locked", "warp_pages_pageable", "warp_pages_page_locked")
 
 
+def available_host_bytes():
+    """(bytes of host memory this process tree can still take, how that was found): the smaller of the kernel's MemAvailable
+    and the container's memory limit minus what it already uses (cgroup v2 memory.max / v1 limit_in_bytes).  A rank that
+    runs the node out of memory is killed without a word and takes the whole job -- the headline with it."""
+    avail, how = None, "unknown"
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail, how = int(line.split()[1]) * 1024, "MemAvailable"
+                break
+    except OSError:
+        pass
+    for lim_f, cur_f in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                         ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            lim = open(lim_f).read().strip()
+            if lim == "max":
+                break
+            room = int(lim) - int(open(cur_f).read())
+            if room < 2 ** 60 and (avail is None or room < avail):
+                avail, how = max(0, room), "cgroup memory limit"
+            break
+        except (OSError, ValueError):
+            continue
+    return avail, how
+
+
+def host_modes_bytes(H, W, itemsize, n_pages):
+    """Host memory one rank's host_modes_measure holds at its peak: the two input pairs and two output sets of the stream
+    (or the pages in and out + the caller's pair), the library's staging rings, and slack."""
+    px = H * W
+    stream = 4 * px * itemsize + 2 * (px * 8 + px * itemsize)
+    paged = 2 * px * itemsize + (2 * n_pages + 1) * px * 2
+    return max(stream, paged) + (3 << 30)
+
+
 def host_modes_measure(ctx, ref, mov, params, n_pairs, n_pages, sync):
     """The numpy -> numpy modes of DESIGN.md section 6 on THIS rank, each between two barriers (`sync`) so that every rank of
     the node runs the same mode at the same time -- these, not the device-resident headline, are what can fail to scale: the
@@ -985,7 +1021,18 @@ def main():
             del flows, warps
         else:
             shared_note = f"skipped: /dev/shm has {room / 2 ** 30:.0f} GiB free, {need / 2 ** 30:.0f} GiB needed"
-    host_rows = {}
+    host_rows, host_skip = {}, None
+    if want_modes and out is not None:
+        # every rank holds ~10 GiB of host arrays in these modes: rank 0 decides for the node (one decision, or the ranks
+        # would part at the barriers) whether they fit beside each other
+        need = host_modes_bytes(H, W, np.dtype(np_dtype).itemsize, args.host_mode_pages) * world
+        room, how = available_host_bytes()
+        verdict = [None if room is None or need <= 0.8 * room else
+                   f"skipped: {world} ranks need {need / 2 ** 30:.0f} GiB of host memory, {room / 2 ** 30:.0f} GiB available ({how})"]
+        if dist is not None:
+            dist.broadcast_object_list(verdict, src=0)
+        if verdict[0]:
+            want_modes, host_skip = False, verdict[0]
     if want_modes and out is not None:
         del out
         out = None
@@ -1062,6 +1109,8 @@ def main():
             "results_to_shared_array_ms": round(shared_ms, 1) if shared_ms is not None else None,
             "results_to_shared_array": shared_note,
         }
+        if host_skip:
+            res["host_modes"] = {"skipped": host_skip}
         if want_modes:
             errs = [r["host_modes_error"] for r in rows if "host_modes_error" in r]
             res["host_modes"] = {"error": errs} if errs else host_modes_report(rows, H, W)

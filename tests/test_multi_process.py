@@ -128,3 +128,16 @@ def test_eight_rank_host_soak_runs_without_a_device():
     assert min(row["per_rank_in_gb_s"]) > 0 and min(row["per_rank_out_gb_s"]) > 0
     assert row["needed_in_gb_s"] == pytest.approx(8 * 2 * 16384 ** 2 * 4 / 0.075 / 1e9, rel=1e-3)
     assert 0 < row["covers"]
+
+
+def test_bench_host_memory_guard_for_the_host_modes():
+    """The numpy -> numpy modes hold ~10 GiB of host arrays per rank; bench.py sizes them against what the node can still
+    give (MemAvailable, the container's limit) before every rank allocates -- a rank killed for memory takes the headline."""
+    sys.path.insert(0, ROOT)
+    import bench
+    room, how = bench.available_host_bytes()
+    assert room is None or (room > 0 and how in ("MemAvailable", "cgroup memory limit"))
+    one = bench.host_modes_bytes(16384, 16384, 4, 8)
+    assert 10 * 2 ** 30 < one < 16 * 2 ** 30                       # cfg3: 4 + 6 GiB of stream arrays, staging, slack
+    assert bench.host_modes_bytes(1000, 1000, 4, 8) < 4 * 2 ** 30    # the slack dominates small workloads
+    assert bench.host_modes_bytes(16384, 16384, 1, 32) > one          # many pages outgrow the stream
