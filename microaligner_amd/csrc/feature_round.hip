@@ -88,7 +88,11 @@ extern "C" int ma_feature_round(ma_ctx* ctx, const void* current, int dtype, int
     }
     if (feat) ma_pool_free(ctx, feat);
     if (rc != MA_OK) return rc;
-    if (res->status == 3) return MA_OK;        // coordinates the device fit does not take: the caller's host statement decides
+    if (res->status == 3) {                    // coordinates the device fit does not take: the caller's host statement decides
+        MA_HIP(hipStreamSynchronize(ctx->stream));          // dog(current)'s report has landed before anybody resets the flags
+        res->zero_max = flags[0] ? 1 : 0;
+        return MA_OK;
+    }
 
     // candidate = cv2.warpAffine(current, estimate), its dog(); an identity estimate compares the current image with itself
     const uint8_t* cand_gate = gate;
