@@ -547,7 +547,69 @@ def host_modes_bytes(H, W, itemsize, n_pages):
     return max(stream, paged) + (3 << 30)
 
 
-def host_modes_measure(ctx, ref, mov, params, n_pairs, n_pages, sync):
+class SoftSync:
+    """Barriers and the exchange of result rows for the host modes over a key-value store of their own (a TCPStore that rank 0
+    hosts), every wait bounded.  The headline has been gathered before these modes start; whatever happens in them -- a rank
+    that fails half way, one that is slow beyond reason -- costs at most `timeout` seconds and a row that says so, never the
+    line: a torch.distributed collective entered by some ranks only waits for half an hour and takes the job with it
+    (a 4-rank rehearsal did exactly that, profiles/r06_notes.md)."""
+
+    def __init__(self, store, world, rank, timeout):
+        self.store, self.world, self.rank, self.timeout, self.n = store, world, rank, float(timeout), 0
+
+    def barrier(self):
+        self.n += 1
+        key = f"ma_hm/barrier/{self.n}"
+        self.store.add(key, 1)
+        deadline = time.monotonic() + self.timeout
+        while int(self.store.add(key, 0)) < self.world:
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"host modes: barrier {self.n} not reached by every rank within {self.timeout:.0f} s")
+            time.sleep(0.002)
+
+    def put_rows(self, rows):
+        self.store.set(f"ma_hm/rows/{self.rank}", json.dumps(rows))
+
+    def get_rows(self):
+        """rank 0: every rank's rows, an error row for a rank that did not deliver in time"""
+        from datetime import timedelta
+        out = []
+        deadline = time.monotonic() + self.timeout
+        for r in range(self.world):
+            key = f"ma_hm/rows/{r}"
+            try:
+                self.store.wait([key], timedelta(seconds=max(1.0, deadline - time.monotonic())))
+                out.append(json.loads(self.store.get(key)))
+            except Exception as e:   # noqa: BLE001
+                out.append({"host_modes_error": f"rank {r} delivered no rows: {e!r}"})
+        return out
+
+
+def host_modes_exchange(dist, world, rank, timeout, port, run):
+    """`run(sync, rows)` measures this rank's host modes into `rows` (a barrier = `sync()`); every rank's rows come back on
+    rank 0 (None on the others).  No torch.distributed collective in here: barriers and rows go through SoftSync, so a rank that fails or
+    stalls costs the others `timeout` seconds at most and shows up as an error row."""
+    soft, mine = None, {}
+    try:
+        if dist is not None:
+            from datetime import timedelta
+            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(port), world, rank == 0,
+                                  timeout=timedelta(seconds=timeout), wait_for_workers=False)
+            soft = SoftSync(store, world, rank, timeout)
+        run(soft.barrier if soft is not None else (lambda: None), mine)      # fills `mine` as it goes: what was measured stays
+    except Exception as e:   # noqa: BLE001 -- a barrier the others did not reach in time, the store itself: this rank leaves the modes
+        import traceback
+        mine["host_modes_error"] = repr(e) + " | " + traceback.format_exc().strip().splitlines()[-1]
+    if soft is None:
+        return [mine]
+    try:
+        soft.put_rows(mine)
+        return soft.get_rows() if rank == 0 else None
+    except Exception as e:   # noqa: BLE001
+        return [{"host_modes_error": f"row exchange failed: {e!r}"}] * world if rank == 0 else None
+
+
+def host_modes_measure(ctx, ref, mov, params, n_pairs, n_pages, sync, res=None):
     """The numpy -> numpy modes of DESIGN.md section 6 on THIS rank, each between two barriers (`sync`) so that every rank of
     the node runs the same mode at the same time -- these, not the device-resident headline, are what can fail to scale: the
     staged path makes three to four passes over host DRAM per payload byte.  Per mode: units, seconds (fill and drain of the
@@ -556,68 +618,87 @@ def host_modes_measure(ctx, ref, mov, params, n_pairs, n_pages, sync):
       stream_pairs_*: parallel.stream_pairs over `n_pairs` pairs (two distinct pairs alternating), flow + warped image into
                       caller arrays; *_pageable: plain numpy arrays in and out; *_page_locked: the same arrays page-locked in
                       place (device.host_register; its cost is reported as host_register_ms_per_gib);
-      warp_pages_*  : Warper.warp_pages, one resident flow over `n_pages` uint16 pages, pageable / page-locked."""
+      warp_pages_*  : Warper.warp_pages, one resident flow over `n_pages` uint16 pages, pageable / page-locked.
+    Every statement that can fail runs inside `guarded`: a failure becomes the row of the mode (or of its set-up) and this rank
+    still passes every barrier the others wait at."""
     import numpy as np
     from microaligner_amd import Warper, device, parallel
     H, W = ref.shape
-    res = {}
-    ins = [(ref, mov), (np.roll(ref, 53, axis=0), np.roll(mov, 53, axis=0))]
-    outs = [(np.zeros((H, W, 2), np.float32), np.zeros((H, W), ref.dtype)) for _ in range(2)]      # touched: no page faults timed
-    seq = [ins[k % 2] for k in range(n_pairs)]
+    res, box = ({} if res is None else res), {}
 
-    def guarded(tag, fn):
-        # every rank passes the same barriers whatever happens to it in between: a failure becomes the mode's row
+    def guarded(tag, fn, needs=()):
+        for k in needs:
+            if k not in box:
+                res.setdefault(tag, {}).setdefault("error", f"not run: the set-up of {k!r} failed")
+                return None
         try:
             return fn()
         except Exception as e:   # noqa: BLE001
             res.setdefault(tag, {})["error"] = repr(e)
             return None
 
+    def setup_stream():
+        ins = [(ref, mov), (np.roll(ref, 53, axis=0), np.roll(mov, 53, axis=0))]
+        outs = [(np.zeros((H, W, 2), np.float32), np.zeros((H, W), ref.dtype)) for _ in range(2)]   # touched: no page faults timed
+        box["ins"], box["outs"], box["seq"] = ins, outs, [ins[k % 2] for k in range(n_pairs)]
+
     def stream(tag):
         def warm():
-            for _ in parallel.stream_pairs(seq[:2], params, warp=True, out=lambda i: outs[i % 2]):   # slots, rings, copy threads
+            outs = box["outs"]
+            for _ in parallel.stream_pairs(box["seq"][:2], params, warp=True, out=lambda i: outs[i % 2]):   # slots, rings, copy threads
                 pass
 
         def timed():
+            ins, outs = box["ins"], box["outs"]
             ctx.transfer_stats(reset=True)
             c0, t0 = time.process_time(), time.perf_counter()
-            for _ in parallel.stream_pairs(seq, params, warp=True, out=lambda i: outs[i % 2]):
+            for _ in parallel.stream_pairs(box["seq"], params, warp=True, out=lambda i: outs[i % 2]):
                 pass
             dt, cpu = time.perf_counter() - t0, time.process_time() - c0
             up, down = ctx.transfer_stats(reset=True)
             res[tag] = {"units": n_pairs, "unit": "pair", "seconds": dt, "payload_bytes": int(up + down), "host_cpu_seconds": cpu,
                         "mode_in": device.transfer_mode(ins[0][0]), "mode_out": device.transfer_mode(outs[0][0]),
                         "direct_in": device.transfer_is_direct(ins[0][0]), "direct_out": device.transfer_is_direct(outs[0][0])}
-        guarded(tag, warm)
+        guarded(tag, warm, needs=("seq",))
         sync()
-        guarded(tag, timed)
+        if "error" not in res.get(tag, {}):
+            guarded(tag, timed, needs=("seq",))
         sync()
 
+    guarded("setup_stream_pairs", setup_stream)
     stream("stream_pairs_pageable")
-    res["transient_page_locking"] = device.transient_pin_stats()       # what the pageable mode did with the caller's arrays
-    t0 = time.perf_counter()
-    locked = [a for pair in ins + outs for a in pair]
-    ok = all([device.host_register(a) for a in locked])
-    reg_s = time.perf_counter() - t0
-    stream("stream_pairs_page_locked")
-    res.setdefault("stream_pairs_page_locked", {})["registered_in_place"] = ok
-    res["host_register_ms_per_gib"] = round(reg_s * 1e3 / (sum(a.nbytes for a in locked) / 2 ** 30), 1)
-    for a in locked:
-        device.host_unregister(a)
-    flow_host = outs[0][0]
-    del ins, seq, locked
+    guarded("transient_page_locking", lambda: res.__setitem__("transient_page_locking", device.transient_pin_stats()))
 
-    rng = np.random.default_rng(5)
-    base = rng.integers(0, 65535, (H, W), dtype=np.uint16)
-    pages = [base ^ np.uint16(257 * k) for k in range(n_pages)]
-    pout = [np.ones_like(base) for _ in range(n_pages)]
-    w = Warper()
-    w.tile_size, w.overlap = params.get("tile_size", 1000), params.get("overlap", 100)
-    w.flow = ctx.asdevice(flow_host)          # the flow of the last streamed pair
-    del outs, flow_host
+    def lock_stream():
+        t0 = time.perf_counter()
+        locked = [a for pair in box["ins"] + box["outs"] for a in pair]
+        box["locked"] = locked
+        box["locked_ok"] = all([device.host_register(a) for a in locked])
+        res["host_register_ms_per_gib"] = round((time.perf_counter() - t0) * 1e3 / (sum(a.nbytes for a in locked) / 2 ** 30), 1)
+    guarded("stream_pairs_page_locked", lock_stream, needs=("seq",))
+    stream("stream_pairs_page_locked")
+    res.setdefault("stream_pairs_page_locked", {})["registered_in_place"] = bool(box.get("locked_ok"))
+
+    def setup_pages():
+        for a in box.pop("locked", []):
+            device.host_unregister(a)
+        flow_host = box["outs"][0][0]
+        for k in ("ins", "seq"):
+            box.pop(k, None)
+        rng = np.random.default_rng(5)
+        base = rng.integers(0, 65535, (H, W), dtype=np.uint16)
+        pages = [base ^ np.uint16(257 * k) for k in range(n_pages)]
+        pout = [np.ones_like(base) for _ in range(n_pages)]
+        w = Warper()
+        w.tile_size, w.overlap = params.get("tile_size", 1000), params.get("overlap", 100)
+        w.flow = ctx.asdevice(flow_host)          # the flow of the last streamed pair
+        box.pop("outs", None)
+        box["pages"], box["pout"], box["warper"] = pages, pout, w
+    guarded("setup_warp_pages", setup_pages, needs=("outs",))
 
     def paged(tag):
         def timed():
+            pages, pout, w = box["pages"], box["pout"], box["warper"]
             ctx.transfer_stats(reset=True)
             c0, t0 = time.process_time(), time.perf_counter()
             w.warp_pages(pages, pout)
@@ -627,17 +708,19 @@ def host_modes_measure(ctx, ref, mov, params, n_pairs, n_pages, sync):
                         "mode_in": "direct" if device.transfer_is_direct(pages[0]) else "staged (pieces: no transient page-locking)",
                         "mode_out": "direct" if device.transfer_is_direct(pout[0]) else "staged (pieces: no transient page-locking)",
                         "direct_in": device.transfer_is_direct(pages[0]), "direct_out": device.transfer_is_direct(pout[0])}
-        guarded(tag, lambda: w.warp_pages(pages[:2], pout[:2]))
+        guarded(tag, lambda: box["warper"].warp_pages(box["pages"][:2], box["pout"][:2]), needs=("warper",))
         sync()
-        guarded(tag, timed)
+        if "error" not in res.get(tag, {}):
+            guarded(tag, timed, needs=("warper",))
         sync()
 
     paged("warp_pages_pageable")
-    ok = all([device.host_register(a) for a in pages + pout])
+    guarded("warp_pages_page_locked",
+            lambda: box.__setitem__("pages_ok", all([device.host_register(a) for a in box["pages"] + box["pout"]])), needs=("warper",))
     paged("warp_pages_page_locked")
-    res.setdefault("warp_pages_page_locked", {})["registered_in_place"] = ok
-    for a in pages + pout:
-        device.host_unregister(a)
+    res.setdefault("warp_pages_page_locked", {})["registered_in_place"] = bool(box.get("pages_ok"))
+    for a in box.get("pages", []) + box.get("pout", []):
+        guarded("cleanup", lambda a=a: device.host_unregister(a))
     return res
 
 
@@ -647,23 +730,32 @@ def host_modes_report(rows, H, W):
     out = {}
     for mode in HOST_MODES:
         per = [r.get(mode) for r in rows]
-        if any(p is None for p in per):
-            continue
-        if any("seconds" not in p for p in per):
-            out[mode] = {"error": [p.get("error") for p in per]}
-            continue
-        slowest = max(p["seconds"] for p in per)
-        units = sum(p["units"] for p in per)
-        out[mode] = {"unit": per[0]["unit"], "units_per_rank": per[0]["units"],
-                     "ms_per_unit_per_rank": [round(p["seconds"] / p["units"] * 1e3, 2) for p in per],
+        good = [p for p in per if p is not None and "seconds" in p]
+        if len(good) < len(per):
+            # a rank without a measurement: its reason (the mode's own failure, the failed set-up, or why the rank left the modes)
+            out[mode] = {"error": [None if (p is not None and "seconds" in p) else
+                                   ((p or {}).get("error") or r.get("host_modes_error") or "no row") for p, r in zip(per, rows)]}
+            if not good:
+                continue
+            out[mode]["ranks_measured"] = [i for i, p in enumerate(per) if p is not None and "seconds" in p]
+        slowest = max(p["seconds"] for p in good)
+        units = sum(p["units"] for p in good)
+        out.setdefault(mode, {}).update({
+                     "unit": good[0]["unit"], "units_per_rank": good[0]["units"],
+                     "ms_per_unit_per_rank": [round(p["seconds"] / p["units"] * 1e3, 2) for p in good],
                      "aggregate_mpix_s": round(units * H * W / slowest / 1e6, 1),
-                     "aggregate_payload_gb_s": round(sum(p["payload_bytes"] for p in per) / slowest / 1e9, 1),
-                     "buffers_moved_directly": [bool(p["direct_in"] and p["direct_out"]) for p in per],
-                     "transfer_mode_in_out": [f"{p.get('mode_in')} / {p.get('mode_out')}" for p in per],
-                     "host_cpu_s_per_unit_per_rank": [round(p.get("host_cpu_seconds", 0.0) / p["units"], 4) for p in per]}
-        if "registered_in_place" in per[0]:
-            out[mode]["registered_in_place"] = [bool(p["registered_in_place"]) for p in per]
-    tp = [r.get("transient_page_locking") for r in rows if r.get("transient_page_locking") is not None]
+                     "aggregate_payload_gb_s": round(sum(p["payload_bytes"] for p in good) / slowest / 1e9, 1),
+                     "buffers_moved_directly": [bool(p["direct_in"] and p["direct_out"]) for p in good],
+                     "transfer_mode_in_out": [f"{p.get('mode_in')} / {p.get('mode_out')}" for p in good],
+                     "host_cpu_s_per_unit_per_rank": [round(p.get("host_cpu_seconds", 0.0) / p["units"], 4) for p in good]})
+        if "registered_in_place" in good[0]:
+            out[mode]["registered_in_place"] = [bool(p.get("registered_in_place")) for p in good]
+    for extra in ("setup_stream_pairs", "setup_warp_pages", "cleanup", "host_modes_error"):
+        errs = {i: (r[extra].get("error") if isinstance(r[extra], dict) else r[extra]) for i, r in enumerate(rows) if r.get(extra)}
+        if errs:
+            out.setdefault("errors", {})[extra] = {f"rank {i}": e for i, e in errs.items()}
+    tp = [r.get("transient_page_locking") for r in rows if r.get("transient_page_locking") is not None
+          and "error" not in r["transient_page_locking"]]
     if tp:
         out["transient_page_locking_per_rank"] = tp
     reg = [r.get("host_register_ms_per_gib") for r in rows if r.get("host_register_ms_per_gib") is not None]
@@ -730,6 +822,21 @@ def launch_ranks(n, argv):
     return rc
 
 
+def finish(dist, rank):
+    """The line is out: a rank that does not come to this barrier within a minute is left behind, not waited for."""
+    if dist is None:
+        return
+    try:
+        from datetime import timedelta
+        dist.monitored_barrier(timeout=timedelta(seconds=60))
+        dist.destroy_process_group()
+    except Exception as e:   # noqa: BLE001
+        print(f"bench.py: rank {rank}: final barrier: {e!r}", file=sys.stderr)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+
+
 def rank_table(dist, world, rank, row):
     """Every rank's row (a small dict) on rank 0, in rank order: per-rank times, device identity, HBM state."""
     if dist is None:
@@ -781,6 +888,9 @@ def main():
                          "scale -- at N = 1 the `variants` legs cover them")
     ap.add_argument("--host-mode-pairs", type=int, default=8, help="pairs per rank of the stream_pairs host modes")
     ap.add_argument("--host-mode-pages", type=int, default=8, help="uint16 pages per rank of the warp_pages host modes")
+    ap.add_argument("--host-mode-timeout", type=float, default=300.0,
+                    help="seconds a rank waits for the others at a barrier of the host modes before it leaves them (the headline "
+                         "has been gathered by then)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduce plumbing only, no GPU work (CPU test of the N-rank launcher)")
     args = ap.parse_args()
@@ -802,7 +912,8 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            from datetime import timedelta
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(minutes=10))
             dist.barrier()
         finally:
             os.dup2(saved_fd, 1)
@@ -852,16 +963,28 @@ def main():
         row = {"rank": rank, "ms_per_step": mine / args.steps * 1e3, "pairs": my_pairs,
                "device": None, "pci_bus_id": None, "units_loaded": sorted(loaded)}
         want_modes = args.host_modes == "on" or (args.host_modes == "auto" and world > 1)
-        if want_modes:       # the plumbing of the host-mode rows (barriers, gather, report) with made-up times
-            for k, mode in enumerate(HOST_MODES):
-                if dist is not None:
-                    dist.barrier()
-                n = args.host_mode_pairs if mode.startswith("stream") else args.host_mode_pages
-                row[mode] = {"units": n, "unit": "pair" if mode.startswith("stream") else "uint16 page",
-                             "seconds": 1e-3 * n * (k + 1) * (1 + 0.01 * rank), "payload_bytes": 1000 * n, "host_cpu_seconds": 1e-4 * n,
-                             "mode_in": "direct" if mode.endswith("locked") else "staged", "mode_out": "direct" if mode.endswith("locked") else "staged",
-                             "direct_in": mode.endswith("locked"), "direct_out": mode.endswith("locked")}
-            row["host_register_ms_per_gib"] = 100.0
+        rows = rank_table(dist, world, rank, row)
+        host_rows_all = None
+        if want_modes:       # the plumbing of the host-mode rows (soft barriers, row exchange, report) with made-up times
+            port = [free_port() if (dist is not None and rank == 0) else 0]
+            if dist is not None:
+                dist.broadcast_object_list(port, src=0)
+
+            def fake_modes(sync, hr):
+                # MA_BENCH_DRY_FAIL="<rank>:<mode index>": that rank fails before that mode's barrier (tests: the line survives)
+                fail = os.environ.get("MA_BENCH_DRY_FAIL", "")
+                fr, fk = (int(v) for v in fail.split(":")) if fail else (-1, -1)
+                for k, mode in enumerate(HOST_MODES):
+                    if rank == fr and k == fk:
+                        raise RuntimeError("injected failure of the dry run")
+                    sync()
+                    n = args.host_mode_pairs if mode.startswith("stream") else args.host_mode_pages
+                    hr[mode] = {"units": n, "unit": "pair" if mode.startswith("stream") else "uint16 page",
+                                "seconds": 1e-3 * n * (k + 1) * (1 + 0.01 * rank), "payload_bytes": 1000 * n, "host_cpu_seconds": 1e-4 * n,
+                                "mode_in": "direct" if mode.endswith("locked") else "staged", "mode_out": "direct" if mode.endswith("locked") else "staged",
+                                "direct_in": mode.endswith("locked"), "direct_out": mode.endswith("locked")}
+                hr["host_register_ms_per_gib"] = 100.0
+            host_rows_all = host_modes_exchange(dist, world, rank, args.host_mode_timeout, port[0], fake_modes)
         rows = rank_table(dist, world, rank, row)
         if rank == 0:
             per = [r["ms_per_step"] for r in rows]
@@ -870,11 +993,9 @@ def main():
                               "config": {"workload": args.workload, "pairs_per_step": pairs_per_step},
                               "ranks": rows, "results_via": "shared memory array written in place by the owning rank",
                               "shared_results_ok": shared_ok,
-                              "host_modes": host_modes_report(rows, 1000, 1000) if want_modes else None,
+                              "host_modes": host_modes_report(host_rows_all, 1000, 1000) if host_rows_all is not None else None,
                               "rank_ms_per_step": {"min": min(per), "mean": sum(per) / len(per), "max": max(per)}}))
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        finish(dist, rank)
         return
 
     import numpy as np
@@ -1021,14 +1142,25 @@ def main():
             del flows, warps
         else:
             shared_note = f"skipped: /dev/shm has {room / 2 ** 30:.0f} GiB free, {need / 2 ** 30:.0f} GiB needed"
-    host_rows, host_skip = {}, None
+    info = device_info(dev_index)
+    # the headline's rows are gathered BEFORE the host modes: nothing that happens in those can cost the line any more
+    rows = rank_table(dist, world, rank, {
+        "rank": rank, "device": dev_index, "pci_bus_id": info["pci_bus_id"], "name": info["name"],
+        "hbm_free_gb": round(info["mem_free"] / 2 ** 30, 1), "hbm_total_gb": round(info["mem_total"] / 2 ** 30, 1),
+        "cpus": (f"{cpu_ranges(bound_cpus)} ({len(bound_cpus)} of {len(all_cpus)}, local to the device)"
+                 if bound_cpus else f"all {len(all_cpus)} (no NUMA binding: topology unknown or single node)"),
+        "pairs": my_pairs, "ms_per_step": round((t1 - t0) / args.steps * 1e3, 3), "clock_ghz": round(clock_ghz, 3),
+        "result": summary})
+    gather_ms = (time.perf_counter() - tg0) * 1e3
+    host_rows_all, host_skip = None, None
     if want_modes and out is not None:
-        # every rank holds ~10 GiB of host arrays in these modes: rank 0 decides for the node (one decision, or the ranks
-        # would part at the barriers) whether they fit beside each other
+        # every rank holds ~10 GiB of host arrays in these modes: rank 0 decides for the node (one decision for all ranks)
+        # whether they fit beside each other, and names the port of the modes' own key-value store (SoftSync)
         need = host_modes_bytes(H, W, np.dtype(np_dtype).itemsize, args.host_mode_pages) * world
         room, how = available_host_bytes()
         verdict = [None if room is None or need <= 0.8 * room else
-                   f"skipped: {world} ranks need {need / 2 ** 30:.0f} GiB of host memory, {room / 2 ** 30:.0f} GiB available ({how})"]
+                   f"skipped: {world} ranks need {need / 2 ** 30:.0f} GiB of host memory, {room / 2 ** 30:.0f} GiB available ({how})",
+                   free_port() if (dist is not None and rank == 0) else 0]
         if dist is not None:
             dist.broadcast_object_list(verdict, src=0)
         if verdict[0]:
@@ -1037,21 +1169,9 @@ def main():
         del out
         out = None
         ctx.trim()        # the headline's pooled buffers go back: the stream needs its own slots and lanes
-        try:
-            host_rows = host_modes_measure(ctx, ref, mov, params, args.host_mode_pairs, args.host_mode_pages,
-                                           (dist.barrier if dist is not None else (lambda: None)))
-        except Exception as e:   # noqa: BLE001 -- never at the cost of the headline; but every rank must leave the barriers
-            import traceback
-            host_rows = {"host_modes_error": repr(e) + " | " + traceback.format_exc().strip().splitlines()[-1]}
-    info = device_info(dev_index)
-    rows = rank_table(dist, world, rank, {**host_rows, 
-        "rank": rank, "device": dev_index, "pci_bus_id": info["pci_bus_id"], "name": info["name"],
-        "hbm_free_gb": round(info["mem_free"] / 2 ** 30, 1), "hbm_total_gb": round(info["mem_total"] / 2 ** 30, 1),
-        "cpus": (f"{cpu_ranges(bound_cpus)} ({len(bound_cpus)} of {len(all_cpus)}, local to the device)"
-                 if bound_cpus else f"all {len(all_cpus)} (no NUMA binding: topology unknown or single node)"),
-        "pairs": my_pairs, "ms_per_step": round((t1 - t0) / args.steps * 1e3, 3), "clock_ghz": round(clock_ghz, 3),
-        "result": summary})
-    gather_ms = (time.perf_counter() - tg0) * 1e3
+        host_rows_all = host_modes_exchange(
+            dist, world, rank, args.host_mode_timeout, verdict[1],
+            lambda sync, rows: host_modes_measure(ctx, ref, mov, params, args.host_mode_pairs, args.host_mode_pages, sync, rows))
     out = None
 
     if rank == 0:
@@ -1111,12 +1231,8 @@ def main():
         }
         if host_skip:
             res["host_modes"] = {"skipped": host_skip}
-        if want_modes:
-            errs = [r["host_modes_error"] for r in rows if "host_modes_error" in r]
-            res["host_modes"] = {"error": errs} if errs else host_modes_report(rows, H, W)
-            for r in rows:       # the per-rank rows stay compact: the modes are reported above
-                for k in HOST_MODES + ("host_register_ms_per_gib", "host_modes_error", "transient_page_locking"):
-                    r.pop(k, None)
+        if host_rows_all is not None:
+            res["host_modes"] = host_modes_report(host_rows_all, H, W)
         def informational(store, name, fn):
             """An informational leg never costs the headline line: a failure is recorded in its place."""
             try:
@@ -1208,9 +1324,7 @@ def main():
             res["roofline_blur_h_solve"] = kernels.get("blur_h_solve")
         res["roofline"] = kernels.get(dominant)
         print(json.dumps(res))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish(dist, rank)
 
 
 if __name__ == "__main__":

@@ -141,3 +141,28 @@ def test_bench_host_memory_guard_for_the_host_modes():
     assert 10 * 2 ** 30 < one < 16 * 2 ** 30                       # cfg3: 4 + 6 GiB of stream arrays, staging, slack
     assert bench.host_modes_bytes(1000, 1000, 4, 8) < 4 * 2 ** 30    # the slack dominates small workloads
     assert bench.host_modes_bytes(16384, 16384, 1, 32) > one          # many pages outgrow the stream
+
+
+def test_bench_line_survives_a_rank_that_fails_inside_the_host_modes():
+    """The headline is gathered before the numpy -> numpy modes start, and those synchronise over a store of their own with
+    bounded waits: a rank that fails half way (here: rank 1 before the third mode's barrier) costs the others the timeout and
+    shows up as an error row -- the line is printed and the job ends.  (A 4-rank rehearsal on one GPU lost its line to a
+    30-minute gloo timeout before this: a torch.distributed collective entered by some ranks only.)"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    env["MA_BENCH_DRY_FAIL"] = "1:2"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "0",
+                        "--dry-run", "--host-mode-timeout", "4"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert time.time() - t0 < 120
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert res["n_gpus"] == 3 and [row["rank"] for row in res["ranks"]] == [0, 1, 2]       # the headline's rows are whole
+    hm = res["host_modes"]
+    for mode in ("stream_pairs_pageable", "stream_pairs_page_locked"):                        # measured by all three before the failure
+        assert len(hm[mode]["ms_per_unit_per_rank"]) == 3 and "error" not in hm[mode]
+    # the third mode: rank 1 never reached its barrier; the others waited out the timeout and left the modes too
+    assert "warp_pages_pageable" in hm and hm["warp_pages_pageable"].get("error")
+    assert "injected failure" in json.dumps(hm["errors"]["host_modes_error"]["rank 1"])
+    assert "barrier 3 not reached" in json.dumps(hm["errors"]["host_modes_error"])
