@@ -555,16 +555,21 @@ class SoftSync:
     (a 4-rank rehearsal did exactly that, profiles/r06_notes.md)."""
 
     def __init__(self, store, world, rank, timeout):
-        self.store, self.world, self.rank, self.timeout, self.n = store, world, rank, float(timeout), 0
+        self.store, self.world, self.rank, self.timeout, self.n, self.name = store, world, rank, float(timeout), 0, "main"
+
+    def section(self, name):
+        """Barriers are numbered within a section: a rank that left one section early meets the others again in the next."""
+        self.name, self.n = name, 0
+        return self
 
     def barrier(self):
         self.n += 1
-        key = f"ma_hm/barrier/{self.n}"
+        key = f"ma/{self.name}/barrier/{self.n}"
         self.store.add(key, 1)
         deadline = time.monotonic() + self.timeout
         while int(self.store.add(key, 0)) < self.world:
             if time.monotonic() > deadline:
-                raise TimeoutError(f"host modes: barrier {self.n} not reached by every rank within {self.timeout:.0f} s")
+                raise TimeoutError(f"{self.name}: barrier {self.n} not reached by every rank within {self.timeout:.0f} s")
             time.sleep(0.002)
 
     def put_rows(self, rows):
@@ -585,23 +590,31 @@ class SoftSync:
         return out
 
 
-def host_modes_exchange(dist, world, rank, timeout, port, run):
+def soft_sync(dist, world, rank, timeout, port):
+    """The key-value store of the informational legs (rank 0 hosts it on `port`, agreed on by a broadcast while the ranks
+    were still in step).  None at N = 1."""
+    if dist is None:
+        return None
+    from datetime import timedelta
+    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(port), world, rank == 0,
+                          timeout=timedelta(seconds=timeout), wait_for_workers=False)
+    return SoftSync(store, world, rank, timeout)
+
+
+def host_modes_exchange(soft, world, rank, run):
     """`run(sync, rows)` measures this rank's host modes into `rows` (a barrier = `sync()`); every rank's rows come back on
-    rank 0 (None on the others).  No torch.distributed collective in here: barriers and rows go through SoftSync, so a rank that fails or
-    stalls costs the others `timeout` seconds at most and shows up as an error row."""
-    soft, mine = None, {}
+    rank 0 (None on the others).  No torch.distributed collective in here: barriers and rows go through SoftSync, so a rank
+    that fails or stalls costs the others one timeout at most and shows up as an error row."""
+    mine = {}
     try:
-        if dist is not None:
-            from datetime import timedelta
-            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(port), world, rank == 0,
-                                  timeout=timedelta(seconds=timeout), wait_for_workers=False)
-            soft = SoftSync(store, world, rank, timeout)
-        run(soft.barrier if soft is not None else (lambda: None), mine)      # fills `mine` as it goes: what was measured stays
+        if world > 1 and soft is None:
+            raise RuntimeError("no store for the informational legs")
+        run(soft.section("host modes").barrier if soft is not None else (lambda: None), mine)   # fills `mine` as it goes
     except Exception as e:   # noqa: BLE001 -- a barrier the others did not reach in time, the store itself: this rank leaves the modes
         import traceback
         mine["host_modes_error"] = repr(e) + " | " + traceback.format_exc().strip().splitlines()[-1]
     if soft is None:
-        return [mine]
+        return [mine] if world == 1 else None
     try:
         soft.put_rows(mine)
         return soft.get_rows() if rank == 0 else None
@@ -984,7 +997,12 @@ def main():
                                 "mode_in": "direct" if mode.endswith("locked") else "staged", "mode_out": "direct" if mode.endswith("locked") else "staged",
                                 "direct_in": mode.endswith("locked"), "direct_out": mode.endswith("locked")}
                 hr["host_register_ms_per_gib"] = 100.0
-            host_rows_all = host_modes_exchange(dist, world, rank, args.host_mode_timeout, port[0], fake_modes)
+            try:
+                soft = soft_sync(dist, world, rank, args.host_mode_timeout, port[0])
+            except Exception as e:   # noqa: BLE001
+                soft = None
+                print(f"bench.py: rank {rank}: store of the informational legs: {e!r}", file=sys.stderr)
+            host_rows_all = host_modes_exchange(soft, world, rank, fake_modes)
         rows = rank_table(dist, world, rank, row)
         if rank == 0:
             per = [r["ms_per_step"] for r in rows]
@@ -1113,35 +1131,6 @@ def main():
         flow, warped = out
         summary = {"pair": my_pairs[-1] if my_pairs else None, "flow_minmax": [float(v) for v in ctx.minmax(flow)],
                    "warped_minmax": [float(v) for v in ctx.minmax(warped)]}
-    # the data plane of a multi-rank job: each rank's download engine writes its (last) flow and warped image straight into
-    # a node-wide shared array (parallel.shared_array; the reference writes pages into its memmapped output,
-    # __main__.py:116-132) -- nothing but reports crosses the control plane
-    shared_ms, shared_note = None, None
-    if world > 1 and out is not None and not args.no_shared_results:
-        from microaligner_amd import parallel
-        name = f"ma_bench_{os.environ.get('MASTER_PORT', '0')}"
-        need = world * (H * W * 8 + H * W * np.dtype(np_dtype).itemsize)
-        try:
-            st = os.statvfs("/dev/shm")
-            room = st.f_bavail * st.f_frsize
-        except OSError:
-            room = 0
-        # one decision for all ranks (a collective inside must never be entered by some ranks only)
-        go = -reduce_max(-(1.0 if (rank != 0 or room > 1.2 * need) else 0.0)) > 0.5
-        if go:
-            ts0 = time.perf_counter()
-            # (unlink=True: the names are gone once every rank has mapped them -- nothing can be left in /dev/shm)
-            flows = parallel.shared_array(name + "_flow", (world, H, W, 2), np.float32, unlink=True)
-            warps = parallel.shared_array(name + "_warp", (world, H, W), np_dtype, unlink=True)
-            out[0].numpy(out=flows[rank])
-            out[1].numpy(out=warps[rank])
-            dist.barrier()
-            shared_ms = (time.perf_counter() - ts0) * 1e3
-            if rank == 0:   # every rank's rows arrived: a strided sample per rank, next to what the rank reports over gloo
-                shared_note = [float(flows[r][::997, ::991].sum()) for r in range(world)]
-            del flows, warps
-        else:
-            shared_note = f"skipped: /dev/shm has {room / 2 ** 30:.0f} GiB free, {need / 2 ** 30:.0f} GiB needed"
     info = device_info(dev_index)
     # the headline's rows are gathered BEFORE the host modes: nothing that happens in those can cost the line any more
     rows = rank_table(dist, world, rank, {
@@ -1152,25 +1141,69 @@ def main():
         "pairs": my_pairs, "ms_per_step": round((t1 - t0) / args.steps * 1e3, 3), "clock_ghz": round(clock_ghz, 3),
         "result": summary})
     gather_ms = (time.perf_counter() - tg0) * 1e3
-    host_rows_all, host_skip = None, None
-    if want_modes and out is not None:
-        # every rank holds ~10 GiB of host arrays in these modes: rank 0 decides for the node (one decision for all ranks)
-        # whether they fit beside each other, and names the port of the modes' own key-value store (SoftSync)
+    # ---- informational legs of a multi-rank run.  The headline's rows are on rank 0; nothing below enters a torch.distributed
+    # collective after the one broadcast of rank 0's decisions: barriers and rows go through SoftSync, every wait bounded.
+    host_rows_all, host_skip, shared_ms, shared_note, soft = None, None, None, None, None
+    all_have_results = reduce_max(0.0 if out is not None else 1.0) < 0.5     # (--pairs-total below N leaves ranks without a pair)
+    want_shared = world > 1 and all_have_results and not args.no_shared_results
+    want_modes = want_modes and all_have_results
+    plan = [None, None, 0]           # why the shared-results leg is skipped, why the host modes are, the store's port
+    if rank == 0 and want_shared:
+        need = world * (H * W * 8 + H * W * np.dtype(np_dtype).itemsize)
+        try:
+            st = os.statvfs("/dev/shm")
+            room = st.f_bavail * st.f_frsize
+        except OSError:
+            room = 0
+        if room <= 1.2 * need:
+            plan[0] = f"skipped: /dev/shm has {room / 2 ** 30:.0f} GiB free, {need / 2 ** 30:.0f} GiB needed"
+    if rank == 0 and want_modes:
+        # every rank holds ~10 GiB of host arrays in these modes: do they fit beside each other
         need = host_modes_bytes(H, W, np.dtype(np_dtype).itemsize, args.host_mode_pages) * world
         room, how = available_host_bytes()
-        verdict = [None if room is None or need <= 0.8 * room else
-                   f"skipped: {world} ranks need {need / 2 ** 30:.0f} GiB of host memory, {room / 2 ** 30:.0f} GiB available ({how})",
-                   free_port() if (dist is not None and rank == 0) else 0]
-        if dist is not None:
-            dist.broadcast_object_list(verdict, src=0)
-        if verdict[0]:
-            want_modes, host_skip = False, verdict[0]
-    if want_modes and out is not None:
+        if room is not None and need > 0.8 * room:
+            plan[1] = f"skipped: {world} ranks need {need / 2 ** 30:.0f} GiB of host memory, {room / 2 ** 30:.0f} GiB available ({how})"
+    if dist is not None:
+        if rank == 0:
+            plan[2] = free_port()
+        dist.broadcast_object_list(plan, src=0)        # the last collective before the line
+        try:
+            soft = soft_sync(dist, world, rank, args.host_mode_timeout, plan[2])
+        except Exception as e:   # noqa: BLE001
+            print(f"bench.py: rank {rank}: store of the informational legs: {e!r}", file=sys.stderr)
+    # the data plane of a multi-rank job: each rank's download engine writes its (last) flow and warped image straight into
+    # a node-wide shared array (parallel.shared_array; the reference writes pages into its memmapped output,
+    # __main__.py:116-132) -- nothing but reports crosses the control plane
+    if want_shared and plan[0]:
+        shared_note = plan[0]
+    elif want_shared:
+        try:
+            from microaligner_amd import parallel
+            if soft is None:
+                raise RuntimeError("no store for the informational legs")
+            sync = soft.section("shared results").barrier
+            name = f"ma_bench_{os.environ.get('MASTER_PORT', '0')}"
+            ts0 = time.perf_counter()
+            # (unlink=True: the names are gone once every rank has mapped them -- nothing can be left in /dev/shm)
+            flows = parallel.shared_array(name + "_flow", (world, H, W, 2), np.float32, unlink=True, barrier=sync)
+            warps = parallel.shared_array(name + "_warp", (world, H, W), np_dtype, unlink=True, barrier=sync)
+            out[0].numpy(out=flows[rank])
+            out[1].numpy(out=warps[rank])
+            sync()
+            shared_ms = (time.perf_counter() - ts0) * 1e3
+            if rank == 0:   # every rank's rows arrived: a strided sample per rank, next to what the rank reports over gloo
+                shared_note = [float(flows[r][::997, ::991].sum()) for r in range(world)]
+            del flows, warps
+        except Exception as e:   # noqa: BLE001 -- informational: the line does not depend on it
+            shared_ms, shared_note = None, f"failed: {e!r}"
+    if want_modes and plan[1]:
+        want_modes, host_skip = False, plan[1]
+    if want_modes:
         del out
         out = None
         ctx.trim()        # the headline's pooled buffers go back: the stream needs its own slots and lanes
         host_rows_all = host_modes_exchange(
-            dist, world, rank, args.host_mode_timeout, verdict[1],
+            soft, world, rank,
             lambda sync, rows: host_modes_measure(ctx, ref, mov, params, args.host_mode_pairs, args.host_mode_pages, sync, rows))
     out = None
 

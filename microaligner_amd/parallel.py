@@ -102,7 +102,7 @@ def _run_local(units: Sequence, mine: List[int], fn: Callable, lanes: int):
     return results
 
 
-def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: bool = False, page_locked=True):
+def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: bool = False, page_locked=True, barrier=None):
     """A node-wide array every rank maps: rank 0 creates `directory/name` (POSIX shared memory by default; any path
     works, e.g. next to the output TIFF), the others open it after a barrier.  COLLECTIVE (every rank calls it with
     the same arguments).  This is where results of a sharded run go instead of being pickled through the control plane:
@@ -118,9 +118,12 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: b
     eight ranks within the host's memory bandwidth.  page_locked="all": the whole array (a rank that
     writes rows of its own choosing).  Where the runtime refuses (no device: gloo tests, --dry-run; a file on disk) the
     array is pageable as before; `arr_is_page_locked(arr)` tells.  MICROALIGNER_SHARED_PAGE_LOCK=0 in the environment turns
-    the default off (hosts with a memlock limit: pinning makes a sparse /dev/shm file resident)."""
+    the default off (hosts with a memlock limit: pinning makes a sparse /dev/shm file resident).
+    barrier: the callable the ranks meet at instead of torch.distributed's barrier (a caller with a bounded-wait barrier of its
+    own, bench.py's informational legs: a rank that fails in here must not hold the others for the process group's timeout)."""
     import numpy as np
     rank, ws = world()
+    barrier = barrier or _barrier
     if page_locked is True and os.environ.get("MICROALIGNER_SHARED_PAGE_LOCK", "1") == "0":
         page_locked = False       # hosts with a memlock limit: the default can be switched off from outside
     # SINGLE NODE: the file is created once and every rank maps that one file.  A launch that spans nodes has ranks whose
@@ -133,13 +136,13 @@ def shared_array(name: str, shape, dtype, directory: str = "/dev/shm", unlink: b
     if rank == 0:
         arr = np.lib.format.open_memmap(path, mode="w+", dtype=np.dtype(dtype), shape=shape)
         arr.flush()
-    _barrier()
+    barrier()
     if rank != 0:
         arr = np.load(path, mmap_mode="r+")
         if arr.shape != shape or arr.dtype != np.dtype(dtype):
             raise ValueError(f"{path}: found {arr.dtype}{arr.shape}, expected {np.dtype(dtype)}{shape}")
     if unlink:
-        _barrier()
+        barrier()
         if rank == 0:
             os.unlink(path)
     if page_locked == "all" or (page_locked and (ws == 1 or arr.ndim < 2)):
