@@ -16,7 +16,8 @@
 
 namespace {
 
-constexpr int KN_TQ = 64, KN_TT = 64, KN_KC = 32, KN_TP = KN_KC + 4;   // T chunk pitch 36 floats: 9 x 16 B, odd
+constexpr int KN_TQ = 64, KN_TT = 64, KN_KC = 32, KN_TP = KN_KC + 4;   // LDS budget of a T chunk (64 rows x 36 floats)
+typedef float kn_f2 __attribute__((ext_vector_type(2)));
 
 struct Top2 { float d0, d1; int i0, i1; };
 
@@ -30,6 +31,7 @@ __device__ __forceinline__ bool before(float da, int ia, float db, int ib) { ret
 
 // qlist / qcount: when given, the kernel serves the query rows qlist[0 .. *qcount) instead of 0 .. nq (the fallback of
 // the filtered search below: the grid is sized for nq and the blocks beyond the list leave at once)
+template <bool PK>
 __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, const float* __restrict__ t, int nq, int nt,
                                                    int dim, int* __restrict__ idx, float* __restrict__ dist,
                                                    const int* __restrict__ qlist, const int* __restrict__ qcount,
@@ -41,22 +43,42 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
     // a list is served by a FEW blocks per train range, each walking the list in steps of the grid (the grid cannot be sized
     // for a count that lives on the device: one block per 64 of ALL queries made 22 000 blocks of which six had work, and
     // their launch cost more than the work -- 150 us per match)
-  for (int qtile = blockIdx.x; qtile * KN_TQ < nq; qtile += gridDim.x) {
+  // all queries: grid (query tiles, train ranges).  A list: grid (train ranges, blocks per range) -- the hardware hands out
+  // blocks x-fastest, so the blocks that HAVE a tile of the list (the first few of the 16 per range) all start at once and the
+  // idle ones follow; with the tiles along x the working blocks sat one in eight among idle ones that each hold half a CU's LDS
+  // for their ~15 us of launch, one load and exit: the last working block started 60 us into a kernel whose blocks run 30 us
+  const int bq = qlist ? blockIdx.y : blockIdx.x, nbq = qlist ? gridDim.y : gridDim.x;
+  const int bs = qlist ? blockIdx.x : blockIdx.y, nbs = qlist ? gridDim.x : gridDim.y;
+  for (int qtile = bq; qtile * KN_TQ < nq; qtile += nbq) {
     __syncthreads();                         // the previous tile's merge has left the LDS buffer
-    // gridDim.y > 1: this block serves the train rows [tbeg, tend) only and leaves its pair per query in `part`
+    // nbs > 1: this block serves the train rows [tbeg, tend) only and leaves its pair per query in `part`
     // (knn2_merge_parts folds them): a handful of queries then occupies the whole chip instead of one CU
-    const int tbeg = gridDim.y > 1 ? (int)blockIdx.y * split_rows : 0;
-    const int tend = gridDim.y > 1 ? min(nt, tbeg + split_rows) : nt;
+    const int tbeg = nbs > 1 ? bs * split_rows : 0;
+    const int tend = nbs > 1 ? min(nt, tbeg + split_rows) : nt;
     const int qp = dim + 4;                  // query pitch; dim % 4 == 0 and (qp / 4) odd when dim % 8 == 0
     float* Qs = lds;                         // [KN_TQ][qp]
-    float* Ts = lds + KN_TQ * qp;            // [2][KN_TT][KN_TP]
+    float* Ts = lds + KN_TQ * qp;            // PK: [2][KN_KC][16 tx][4 cc], else [2][KN_TT][KN_TP]
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int q0 = qtile * KN_TQ;
-    for (int e = tid; e < KN_TQ * (dim / 4); e += 256) {
-        const int row = e / (dim / 4), k4 = e - row * (dim / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + row < nq) v = reinterpret_cast<const float4*>(q + (size_t)(qlist ? qlist[q0 + row] : q0 + row) * dim)[k4];
-        *reinterpret_cast<float4*>(Qs + row * qp + 4 * k4) = v;
+    // the tile's query rows -> LDS: the list's row numbers first (one load per row, not one in front of every 16-byte load of
+    // the row), then four loads in flight per thread -- a block of the list lives ~100 us, a load after a load after a load
+    // was a fifth of that
+    __shared__ int qrow[KN_TQ];
+    if (tid < KN_TQ) qrow[tid] = q0 + tid < nq ? (qlist ? qlist[q0 + tid] : q0 + tid) : -1;
+    __syncthreads();
+    for (int e0 = tid; e0 < KN_TQ * (dim / 4); e0 += 256 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = e0 + 256 * u, row = e / (dim / 4), k4 = e - row * (dim / 4);
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < KN_TQ * (dim / 4) && qrow[row] >= 0) v[u] = reinterpret_cast<const float4*>(q + (size_t)qrow[row] * dim)[k4];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = e0 + 256 * u, row = e / (dim / 4), k4 = e - row * (dim / 4);
+            if (e < KN_TQ * (dim / 4)) *reinterpret_cast<float4*>(Qs + row * qp + 4 * k4) = v[u];
+        }
     }
     Top2 best[4];
 #pragma unroll
@@ -64,7 +86,13 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
 
     // the train rows pass through two LDS buffers: the next chunk (64 rows x 32 dimensions) is loaded into registers before the
     // current one is consumed and written behind it -- one barrier per chunk, no load latency between chunks (the fallback of
-    // the filtered search spent two thirds of its time there: 35 chunks of 4 us for a few dozen queries)
+    // the filtered search spent two thirds of its time there: 35 chunks of 4 us for a few dozen queries).
+    // A chunk lies in LDS as [dimension][tx][cc] -- the four rows tx, tx + 16, tx + 32, tx + 48 a thread serves, adjacent -- so
+    // that ONE 16-byte read gives a thread its four train values of a dimension as two register pairs, and the arithmetic runs
+    // on PACKED float32 instructions (v_pk_add_f32 / v_pk_mul_f32: two accumulators per instruction, each component rounded as
+    // the scalar instruction rounds it; the query value is broadcast into both halves).  The kernel is bound by instruction
+    // issue: scalar float32 instructions issue every 7.8 cycles from one wave per SIMD (tools/ubench_valu.hip), which is what
+    // the few blocks of the fallback get -- 192 of them per four dimensions before, 96 packed ones now.
     const int cpt = (dim + KN_KC - 1) / KN_KC;                       // chunks per train tile
     const int ntile = tend > tbeg ? (tend - tbeg + KN_TT - 1) / KN_TT : 0, nchunk = ntile * cpt;
     float4 stage[2];
@@ -77,6 +105,63 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
             if (t0 + row < tend && k0 + 4 * k4 < dim) stage[u] = reinterpret_cast<const float4*>(t + (size_t)(t0 + row) * dim + k0)[k4];
         }
     };
+  if constexpr (PK) {
+    auto commit = [&](int c) {
+        float* dst = Ts + (c & 1) * KN_TT * KN_KC;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int e = tid + 256 * u, row = e >> 3, k4 = e & 7;
+            float* o = dst + (4 * k4) * KN_TT + (row & 15) * 4 + (row >> 4);
+            o[0] = stage[u].x; o[KN_TT] = stage[u].y; o[2 * KN_TT] = stage[u].z; o[3 * KN_TT] = stage[u].w;
+        }
+    };
+    if (nchunk > 0) { fetch(0); commit(0); }
+    __syncthreads();                         // Qs and the first chunk complete
+    kn_f2 acc[4][2];                         // acc[r][p]: rows tx + 32 p (.x) and tx + 32 p + 16 (.y) against query ty * 4 + r
+    for (int c = 0; c < nchunk; c++) {
+        const int t0 = tbeg + (c / cpt) * KN_TT, kcix = c % cpt, k0 = kcix * KN_KC;
+        if (c + 1 < nchunk) fetch(c + 1);
+        if (kcix == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { acc[r][0] = (kn_f2)(0.f); acc[r][1] = (kn_f2)(0.f); }
+        }
+        const float* Tc = Ts + (c & 1) * KN_TT * KN_KC;
+        const int kc = min(KN_KC, dim - k0) / 4;
+        for (int k4 = 0; k4 < kc; k4++) {
+            float4 qv[4], tv[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) qv[r] = *reinterpret_cast<const float4*>(Qs + (ty * 4 + r) * qp + k0 + 4 * k4);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) tv[kk] = *reinterpret_cast<const float4*>(Tc + (4 * k4 + kk) * KN_TT + tx * 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                const kn_f2 ta = {tv[kk].x, tv[kk].y}, tb = {tv[kk].z, tv[kk].w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    // d2 = d2 + d*d, product and sum rounded separately (the file is built with -ffp-contract=off):
+                    // the definition sparse_cpu.knn2_sequential restates with numpy, bit for bit
+                    const float qs = kk == 0 ? qv[r].x : kk == 1 ? qv[r].y : kk == 2 ? qv[r].z : qv[r].w;
+                    const kn_f2 q2 = {qs, qs};
+                    kn_f2 d;
+                    d = q2 - ta; acc[r][0] = acc[r][0] + d * d;
+                    d = q2 - tb; acc[r][1] = acc[r][1] + d * d;
+                }
+            }
+        }
+        if (kcix == cpt - 1) {
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                const int j = t0 + tx + 16 * cc;
+                if (j < tend) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) top2_push(best[r], (cc & 1) ? acc[r][cc >> 1].y : acc[r][cc >> 1].x, j);
+                }
+            }
+        }
+        if (c + 1 < nchunk) commit(c + 1);
+        __syncthreads();
+    }
+  } else {
     auto commit = [&](int c) {
         float* dst = Ts + (c & 1) * KN_TT * KN_TP;
 #pragma unroll
@@ -131,6 +216,7 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
         if (c + 1 < nchunk) commit(c + 1);
         __syncthreads();
     }
+  }
     // merge the 16 partial results of every query row (Qs is free now)
     __syncthreads();
     float* cd = lds;                                         // [64][16][2] distances
@@ -152,8 +238,8 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
             if (before(d, i, d0, i0)) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
             else if (before(d, i, d1, i1)) { d1 = d; i1 = i; }
         }
-        if (gridDim.y > 1) {
-            part[(size_t)blockIdx.y * cap + q0 + tid] = make_float4(d0, d1, __int_as_float(i0), __int_as_float(i1));
+        if (nbs > 1) {
+            part[(size_t)bs * cap + q0 + tid] = make_float4(d0, d1, __int_as_float(i0), __int_as_float(i1));
         } else {
             const size_t o = (size_t)(qlist ? qlist[q0 + tid] : q0 + tid) * 2;
             idx[o] = i0;
@@ -165,31 +251,43 @@ __global__ __launch_bounds__(256) void knn2_kernel(const float* __restrict__ q, 
   }
 }
 
-// the pairs the train splits of knn2_kernel left for list position p -> the pair of query qlist[p]
+// the pairs the train splits of knn2_kernel left for list position p -> the pair of query qlist[p].  One WAVE per position:
+// the lanes take the splits 64 apart and the partial pairs are folded across the wave (a strict total order on (distance,
+// index) and disjoint index sets: the two smallest do not depend on the order of the folding).  A thread per position read
+// its 179 partial results one after the other -- 96 us for the top level's 350 queries, latency all of it.
 __global__ __launch_bounds__(256) void knn2_merge_parts(const float4* __restrict__ part, int cap, int nsplit,
                                                         const int* __restrict__ qlist, const int* __restrict__ qcount,
                                                         int* __restrict__ idx, float* __restrict__ dist)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= *qcount) return;
-    float d0 = FLT_MAX, d1 = FLT_MAX;
-    int i0 = 0x7fffffff, i1 = 0x7fffffff;
-    for (int s = 0; s < nsplit; s++) {
-        const float4 v = part[(size_t)s * cap + p];
-        const float d[2] = {v.x, v.y};
-        const int i[2] = {__float_as_int(v.z), __float_as_int(v.w)};
+    const int lane = threadIdx.x & 63, n = *qcount;
+    for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += gridDim.x * 4) {      // wave-uniform
+        float d0 = FLT_MAX, d1 = FLT_MAX;
+        int i0 = 0x7fffffff, i1 = 0x7fffffff;
+        auto push = [&](float d, int i) {
+            if (i == 0x7fffffff) return;
+            if (before(d, i, d0, i0)) { d1 = d0; i1 = i0; d0 = d; i0 = i; }
+            else if (before(d, i, d1, i1)) { d1 = d; i1 = i; }
+        };
+        for (int s = lane; s < nsplit; s += 64) {
+            const float4 v = part[(size_t)s * cap + p];
+            push(v.x, __float_as_int(v.z));
+            push(v.y, __float_as_int(v.w));
+        }
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            if (i[e] == 0x7fffffff) continue;
-            if (before(d[e], i[e], d0, i0)) { d1 = d0; i1 = i0; d0 = d[e]; i0 = i[e]; }
-            else if (before(d[e], i[e], d1, i1)) { d1 = d[e]; i1 = i[e]; }
+        for (int off = 32; off; off >>= 1) {
+            const float e0 = __shfl_xor(d0, off), e1 = __shfl_xor(d1, off);
+            const int j0 = __shfl_xor(i0, off), j1 = __shfl_xor(i1, off);
+            push(e0, j0);
+            push(e1, j1);
+        }
+        if (lane == 0) {
+            const size_t o = (size_t)qlist[p] * 2;
+            idx[o] = i0;
+            idx[o + 1] = i1;
+            dist[o] = d0;
+            dist[o + 1] = d1;
         }
     }
-    const size_t o = (size_t)qlist[p] * 2;
-    idx[o] = i0;
-    idx[o + 1] = i1;
-    dist[o] = d0;
-    dist[o + 1] = d1;
 }
 
 // ---- filtered search: FP32 MFMA shortlist, exact re-evaluation, certificate, exact fallback --------------------------
@@ -809,18 +907,27 @@ static int knn2_exact(ma_ctx* ctx, const float* query, int nq, const float* trai
     size_t lds = (size_t)(KN_TQ * (dim + 4) + 2 * KN_TT * KN_TP) * sizeof(float);
     lds = std::max(lds, (size_t)KN_TQ * 16 * 4 * sizeof(float));   // the final merge reuses the buffer
     MA_REQUIRE(lds <= 160 * 1024, "descriptor length out of range");
-    if (lds > 64 * 1024)
-        MA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(knn2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MaProfScope ps(ctx, MA_K_OTHER, (double)nq);
     const int split_rows = nsplit > 1 ? ((nt + nsplit - 1) / nsplit + KN_TT - 1) / KN_TT * KN_TT : nt;
     if (nsplit > 1) nsplit = (nt + split_rows - 1) / split_rows;
     // all queries: a block per 64 of them; a list (count on the device): at most 16 blocks per train range walk it
     const int qblocks = (nq + KN_TQ - 1) / KN_TQ;
-    hipLaunchKernelGGL(knn2_kernel, dim3(qlist ? std::min(qblocks, 16) : qblocks, nsplit), dim3(256), lds, ctx->stream, query, train,
-                       nq, nt, dim, idx_out, dist_out, qlist, qcount, split_rows, part);
+    const dim3 grid = qlist ? dim3(nsplit, std::min(qblocks, 16)) : dim3(qblocks, nsplit);
+    // the same sums on packed float32 instructions for the LIST of the filtered search -- a few blocks, a wave per SIMD: half
+    // the instructions, 120 -> 99 us for the coarse levels' lists; with more blocks the scalar form is the faster one (8.5 against
+    // 9.2 ms for all 22 800 x 22 900 descriptors of the top level, tools/bench_match.py, three alternations on one box)
+    const bool packed = qlist != nullptr;
+    const void* fn = packed ? reinterpret_cast<const void*>(knn2_kernel<true>) : reinterpret_cast<const void*>(knn2_kernel<false>);
+    if (lds > 64 * 1024) MA_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (packed)
+        hipLaunchKernelGGL(knn2_kernel<true>, grid, dim3(256), lds, ctx->stream, query, train, nq, nt, dim, idx_out, dist_out, qlist,
+                           qcount, split_rows, part);
+    else
+        hipLaunchKernelGGL(knn2_kernel<false>, grid, dim3(256), lds, ctx->stream, query, train, nq, nt, dim, idx_out, dist_out, qlist,
+                           qcount, split_rows, part);
     if (nsplit > 1)
-        hipLaunchKernelGGL(knn2_merge_parts, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, part, nq, nsplit, qlist, qcount,
-                           idx_out, dist_out);
+        hipLaunchKernelGGL(knn2_merge_parts, dim3(std::min((nq + 3) / 4, 1024)), dim3(256), 0, ctx->stream, part, nq, nsplit, qlist,
+                           qcount, idx_out, dist_out);
     MA_HIP(hipGetLastError());
     return MA_OK;
 }
@@ -877,7 +984,7 @@ extern "C" int ma_knn2_l2_ex(ma_ctx* ctx, const float* query, int nq, const floa
     // train ranges of the exact fallback.  A block works through a 64-query tile whatever the number of real queries in it, so
     // the few uncertified queries (one to six tiles) are spread over the chip by cutting the train set finely: one 64-row tile
     // per range where the partial results (16 bytes per query and range) stay within 256 MB
-    const int fsplit = (int)std::max<size_t>(1, std::min<size_t>({(size_t)256, (size_t)nt / 64, ((size_t)256 << 20) / ((size_t)nq * 16)}));
+    const int fsplit = (int)std::max<size_t>(1, std::min<size_t>({(size_t)256, ((size_t)nt + 63) / 64, ((size_t)256 << 20) / ((size_t)nq * 16)}));
     const size_t b_nt2 = ma_align_up((size_t)nt * 4, 256), b_ci = ma_align_up((size_t)nsplit * nq * KM_K * 4, 256),
                  b_a4 = ma_align_up((size_t)nsplit * nq * 4, 256), b_ql = ma_align_up((size_t)nq * 4, 256),
                  b_part = fsplit > 1 ? (size_t)fsplit * nq * sizeof(float4) : 0;
