@@ -492,20 +492,39 @@ __global__ __launch_bounds__(256) void km_refine(const float* __restrict__ q, co
     if (qi < nq && c < nsplit * KM_K) {
         const int s = c / KM_K, e = c - s * KM_K;
         j = cand_idx[((size_t)s * nq + qi) * KM_K + e];
-        if (j != 0x7fffffff) {
-            const float4* qr = reinterpret_cast<const float4*>(q + (size_t)qi * dim);
-            const float4* tr = reinterpret_cast<const float4*>(t + (size_t)j * dim);
-            float a = 0.f;
-            for (int k = 0; k < dim / 4; k++) {
-                const float4 x = qr[k], y = tr[k];
-                float d;
-                d = x.x - y.x; a = a + d * d;
-                d = x.y - y.y; a = a + d * d;
-                d = x.z - y.z; a = a + d * d;
-                d = x.w - y.w; a = a + d * d;
+    }
+    if (qi < nq && (j != 0x7fffffff || c == 0)) {
+        // the loads of a row ten at a time, then the sums in their order: one load in front of every four terms was one
+        // memory latency per 16 bytes, fifty in a row (205 us for the top level's 730 000 candidates).  Thread 0 of a query
+        // also takes the query's squared norm for the certificate from the same registers (the fmaf chain of km_norms).
+        const bool has = j != 0x7fffffff;
+        const float4* qr = reinterpret_cast<const float4*>(q + (size_t)qi * dim);
+        const float4* tr = reinterpret_cast<const float4*>(t + (size_t)(has ? j : 0) * dim);
+        constexpr int KB = 10;
+        const int n4 = dim / 4;
+        float a = 0.f;
+        for (int k0 = 0; k0 < n4; k0 += KB) {
+            float4 x[KB], y[KB];
+#pragma unroll
+            for (int u = 0; u < KB; u++) {
+                const int k = min(k0 + u, n4 - 1);
+                x[u] = qr[k];
+                y[u] = tr[k];
             }
-            d2 = a;
+#pragma unroll
+            for (int u = 0; u < KB; u++) {
+                if (k0 + u < n4) {
+                    float d;
+                    d = x[u].x - y[u].x; a = a + d * d;
+                    d = x[u].y - y[u].y; a = a + d * d;
+                    d = x[u].z - y[u].z; a = a + d * d;
+                    d = x[u].w - y[u].w; a = a + d * d;
+                    qn = __builtin_fmaf(x[u].x, x[u].x, qn); qn = __builtin_fmaf(x[u].y, x[u].y, qn);
+                    qn = __builtin_fmaf(x[u].z, x[u].z, qn); qn = __builtin_fmaf(x[u].w, x[u].w, qn);
+                }
+            }
         }
+        if (has) d2 = a;
     }
     sd[tid] = d2;
     si[tid] = j;
@@ -524,14 +543,6 @@ __global__ __launch_bounds__(256) void km_refine(const float* __restrict__ q, co
     // g (|t_j|^2 + 2 |q| |t_j|), g = (dim + 4) u (two fmaf chains of dim terms and one more rounding); the defining sum
     // s_j is at least (T_j + |q|^2) (1 - (dim + 3) u) (a sum of non-negative terms, three roundings per term and one
     // per addition).  Norms enter through their computed values, inflated by their own bound.
-    {
-        const float4* qr = reinterpret_cast<const float4*>(q + (size_t)qi * dim);
-        for (int k = 0; k < dim / 4; k++) {
-            const float4 x = qr[k];
-            qn = __builtin_fmaf(x.x, x.x, qn); qn = __builtin_fmaf(x.y, x.y, qn);
-            qn = __builtin_fmaf(x.z, x.z, qn); qn = __builtin_fmaf(x.w, x.w, qn);
-        }
-    }
     float a4 = INFINITY;
     for (int s = 0; s < nsplit; s++) a4 = fminf(a4, cand_a4[(size_t)s * nq + qi]);
     const double u = 5.9604644775390625e-8, g = (dim + 4) * u * 1.01, dl = (dim + 3) * u * 1.01;
