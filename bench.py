@@ -422,6 +422,75 @@ def lanes_leg(lanes, steps, device, dref, dmov, params, tile, overlap):
     return (max(b for _, b in spans) - min(a for a, _ in spans)) / (lanes * steps)
 
 
+def tile_lanes_leg(lanes, steps, device, work, params, use_features):
+    """Seconds per mosaic tile (cfg5) with `lanes` tiles in flight on one GPU: each lane -- own context (HIP stream, workspace,
+    pools), own host thread -- takes every lanes-th tile of `work` and runs the whole composition on it (affine initialisation,
+    transform, optical-flow refinement, warp), `steps` passes over its share.  A 4096^2 tile leaves most of the chip idle at
+    its coarse levels and during the feature stage's synchronisations; a second tile fills that."""
+    import threading
+    import numpy as np
+    from microaligner_amd import FeatureRegistrator, OptFlowRegistrator, Warper
+    from microaligner_amd.device import Context, use_context
+    lanes = max(1, min(lanes, len(work)))
+    bar, spans, errors = threading.Barrier(lanes), [], []
+
+    def lane(i):
+        ctx = None
+        try:
+            ctx = Context(device)
+            with use_context(ctx):
+                items = work[i::lanes]
+                freg = None
+                if use_features:
+                    freg = FeatureRegistrator()
+                    freg.verbose = False
+                reg = OptFlowRegistrator()
+                reg.verbose = False
+                for k, v in params.items():
+                    setattr(reg, k, v)
+                w = Warper()
+                w.tile_size, w.overlap = reg.tile_size, reg.overlap
+
+                def one(dref, dmov, inv_affine, _host):
+                    if freg is not None:
+                        freg.ref_img, freg.mov_img = dref, dmov
+                        t_mat = freg.register()
+                        m = ctx.warp_affine(dmov, np.linalg.pinv(np.vstack([t_mat, [0, 0, 1]])))
+                    else:
+                        m = ctx.warp_affine(dmov, inv_affine)
+                    reg.ref_img, reg.mov_img = dref, m
+                    flow = reg.register()
+                    w.image, w.flow = m, flow
+                    return w.warp()
+
+                for it in items:
+                    one(*it)
+                ctx.sync()
+                bar.wait(timeout=600)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    for it in items:
+                        one(*it)
+                ctx.sync()
+                spans.append((t0, time.perf_counter()))
+        except BaseException as e:  # a failed lane must not leave the others waiting at the barrier
+            errors.append(e)
+            bar.abort()
+        finally:
+            if ctx is not None:
+                ctx.close()
+
+    th = [threading.Thread(target=lane, args=(i,)) for i in range(lanes)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors or len(spans) != lanes:
+        first = next((e for e in errors if not isinstance(e, threading.BrokenBarrierError)), errors[0] if errors else None)
+        raise RuntimeError(f"a lane failed: {first!r}")
+    return (max(b for _, b in spans) - min(a for a, _ in spans)) / (len(work) * steps), lanes
+
+
 def host_inclusive_leg(steps, ref, mov, params):
     """numpy in -> numpy out through the drop-in API (optflow_registrator.py:93,173; warper.py:53): H2D of both
     images, register(), warp(), D2H of the flow and the warped image, per pair."""
@@ -1344,6 +1413,14 @@ def main():
                 informational(V, "page_warp", lambda: page_warp_leg(args.page_warps, H, W, reg.tile_size, reg.overlap))
             if args.lanes > 1 and inv_affine is None:
                 informational(V, f"lanes{args.lanes}", leg_lanes)
+        if world == 1 and wl.get("affine") and not args.no_variants and args.lanes > 1 and len(work) > 1:
+            def leg_tile_lanes():
+                tl, n = tile_lanes_leg(args.lanes, args.steps, ctx.device, work, params, freg is not None)
+                return {"ms_per_tile": round(tl * 1e3, 3), "value": round(H * W / tl / 1e6, 2), "unit": "Mpix/s", "tiles_in_flight": n,
+                        "what": "the same tiles, the same statements, `tiles_in_flight` of them at a time on one GPU (one context "
+                                "and host thread each): what parallel.align_pairs(lanes=...) does; the headline runs them one "
+                                "after the other"}
+            informational(res.setdefault("variants", {}), f"tile_lanes{args.lanes}", leg_tile_lanes)
         if world == 1 and not args.no_cpu_baseline and not args.pairs_total:
             set_affinity(all_cpus)      # the CPU baseline uses every core of the host, not just the GPU's node
             # a bounded sample: the full workload where >= 128 CPUs can really run, else 8192^2 (the GPU boxes of this pool grant
