@@ -472,10 +472,10 @@ def test_feature_registrator_helpers():
         f.register()
 
 
-def _lattice_case(rng, trial):
+def _lattice_case(rng, trial, big=False):
     """Matched keypoint pairs as FeatureRegistrator meets them: integer pixel positions, a similarity (every third trial a pure
     integer translation, under which residuals of EXACTLY the 3-px threshold occur) plus noise, a share of outliers."""
-    n = int(rng.integers(5, 2500))
+    n = int(rng.integers(9000, 12000)) if big else int(rng.integers(5, 2500))
     th, sc = rng.uniform(-0.05, 0.05), rng.uniform(0.95, 1.05)
     M = np.array([[sc * np.cos(th), -sc * np.sin(th), float(rng.integers(-30, 30))],
                   [sc * np.sin(th), sc * np.cos(th), float(rng.integers(-30, 30))]])
@@ -558,7 +558,9 @@ def test_device_ratio_test_and_ransac_equal_the_host_statement(ctx):
     residuals, with outliers, duplicated points, and with too few matches."""
     rng = np.random.default_rng(1)
     for trial in range(150):
-        mov, ref = _lattice_case(rng, trial)                 # query (moving) points and where each one's match lies
+        # (every 25th case has more than 8192 good matches: several passes of the single-block kernels per thread)
+        big = trial % 25 == 11
+        mov, ref = _lattice_case(rng, trial, big)            # query (moving) points and where each one's match lies
         nq = len(mov)
         if trial % 10 == 4:
             mov[: nq // 2] = mov[0]                          # many coinciding points: degenerate samples
@@ -572,7 +574,7 @@ def test_device_ratio_test_and_ransac_equal_the_host_statement(ctx):
         train[perm] = ref
         idx = np.stack([perm, rng.integers(0, nt, nq)], 1).astype(np.int32)
         d1 = rng.uniform(0.5, 2.0, nq).astype(np.float32)
-        good_share = rng.uniform(0.0, 1.0) if trial % 6 else 0.002
+        good_share = 1.0 if big else rng.uniform(0.0, 1.0) if trial % 6 else 0.002
         d0 = np.where(rng.random(nq) < good_share, d1 * rng.uniform(0.01, 0.2499, nq), d1 * rng.uniform(0.2501, 1.0, nq)).astype(np.float32)
         if trial % 4 == 1:
             d0[::7] = (d1[::7] * np.float32(0.25))           # sqrt(d0) == 0.5 sqrt(d1) up to float32 rounding: the strict test
