@@ -685,6 +685,15 @@ def test_affine_init_then_optical_flow_refine():
     assert len(streamed) == 3
     for final3, T3, flow3 in (streamed[0], streamed[2]):
         assert np.array_equal(final3, final) and np.array_equal(T3, T) and np.array_equal(flow3, flow)
+    # ... and with three tiles IN FLIGHT (a context and a host thread per lane: what bench.py's variants.tile_lanesN times for
+    # BASELINE cfg5; FeatureRegistrator's fused rounds, the cached descriptor tables and the pools are per context): same bits
+    laned = parallel.align_pairs([(ref, mov), (ref, mov[::-1].copy()), (ref, mov), (ref, mov[::-1].copy()), (ref, mov)],
+                                 dict(num_pyr_lvl=2, tile_size=500), of_params, lanes=3)
+    assert len(laned) == 5
+    for k in (0, 2, 4):
+        assert np.array_equal(laned[k][0], final) and np.array_equal(laned[k][1], T) and np.array_equal(laned[k][2], flow)
+    for k in (1, 3):
+        assert all(np.array_equal(a, b) for a, b in zip(laned[k], streamed[1]))
     inner = (slice(120, -120), slice(120, -120))
     err = [np.abs(a[inner].astype(np.float64) - ref[inner]).mean() for a in (mov, affine, final)]
     assert err[1] < 0.5 * err[0] and err[2] < 0.8 * err[1]
