@@ -454,9 +454,12 @@ __global__ __launch_bounds__(KC_T) void kp_cut_kernel(const int* __restrict__ ch
 {
     __shared__ int wsum[KC_T / 64];
     __shared__ int sc[3];
+    __shared__ int hist[256];
+    static_assert(KC_T == 256, "one histogram bin per thread");
     const int t = blockIdx.x, tid = threadIdx.x;
+    hist[tid] = tile_hist[t * 256 + tid];          // (thread 0 walked the 255 bins in global memory, one load after the other: 15 us)
+    __syncthreads();
     if (tid == 0) {
-        const int* hist = tile_hist + t * 256;
         int total = 0;
         for (int k = 1; k < 256; k++) total += hist[k];
         int sstar = 0, need_eq = 0;
@@ -477,9 +480,15 @@ __global__ __launch_bounds__(KC_T) void kp_cut_kernel(const int* __restrict__ ch
         const int c = c0 + tid;
         int gt = 0, eq = 0;
         if (c < nch) {
-            const int* h = chunk_hist + ((size_t)t * nch + c) * 256;
-            for (int k = sstar + 1; k < 256; k++) gt += h[k];
-            eq = sstar > 0 ? h[sstar] : 0;
+            const int4* h4 = reinterpret_cast<const int4*>(chunk_hist + ((size_t)t * nch + c) * 256);
+#pragma unroll 16
+            for (int k4 = 0; k4 < 64; k4++) {        // all 64 loads independent of sstar: in flight together
+                const int4 v = h4[k4];
+                const int k = 4 * k4;
+                gt += (k > sstar ? v.x : 0) + (k + 1 > sstar ? v.y : 0) + (k + 2 > sstar ? v.z : 0) + (k + 3 > sstar ? v.w : 0);
+                eq += (k == sstar ? v.x : 0) + (k + 1 == sstar ? v.y : 0) + (k + 2 == sstar ? v.z : 0) + (k + 3 == sstar ? v.w : 0);
+            }
+            if (sstar <= 0) eq = 0;
         }
         int eq_tot, sel_tot;
         const int eq_base = eq_run + ks_block_exscan<KC_T>(eq, wsum, eq_tot);
@@ -652,7 +661,7 @@ struct FastScratch {
         const size_t b_ch = (size_t)nt * nch_out * 256 * sizeof(int), b_keys = (size_t)nt * KS_CAP * sizeof(unsigned long long),
                      b_th = (size_t)nt * 256 * sizeof(int), b_cb = (size_t)nt * nch_out * 2 * sizeof(int),
                      b_cut = (size_t)nt * 4 * sizeof(int);
-        return ma_align_up(2 * map, 8) + b_keys + b_ch + b_th + b_cb + b_cut + 64;
+        return ma_align_up(2 * map, 16) + b_keys + b_ch + b_th + b_cb + b_cut + 64;
     }
     void place(void* buf, int nt, int Pi)
     {
@@ -660,7 +669,7 @@ struct FastScratch {
         bytes = size(nt, Pi, nch);
         raw = (int*)buf;
         nms = raw + (size_t)nt * npx;
-        keys = (unsigned long long*)((char*)buf + ma_align_up(2 * map, 8));
+        keys = (unsigned long long*)((char*)buf + ma_align_up(2 * map, 16));
         chunk_hist = (int*)(keys + (size_t)nt * KS_CAP);
         tile_hist = chunk_hist + (size_t)nt * nch * 256;
         chunk_base = tile_hist + (size_t)nt * 256;
