@@ -469,6 +469,15 @@ int ma_cut_tiles_u8(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int
 int ma_feature_extract(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int threshold, int limit,
                        const double* const* weights_host, const int* radii, const double* cos_sin_host, const double* offs_host,
                        size_t workspace_bytes, int capacity, float* desc_out, double* pts_out, int* resp_out, int* n_out_host);
+/* The same work ENQUEUED: no synchronisation, the number of keypoints lands in n_out_pinned -- page-locked host memory
+ * (ma_host_alloc) -- in stream order; the caller reads it after waiting for the ctx's stream or for an event recorded behind the
+ * call (ma_event_record / ma_event_sync).  This is how FeatureRegistrator computes the REFERENCE image's features of every level on
+ * a second ctx while the first one works through the moving image's coarse levels (feature_registrator.py:70-76 computes them up
+ * front; nothing in a level's rounds needs the next level's reference features). */
+int ma_feature_extract_enqueue(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int threshold, int limit,
+                               const double* const* weights_host, const int* radii, const double* cos_sin_host,
+                               const double* offs_host, size_t workspace_bytes, int capacity, float* desc_out, double* pts_out,
+                               int* resp_out, int* n_out_pinned);
 /* ma_daisy_describe: DAISY descriptors (radius 21, 3 rings x 8 locations + centre, 8 orientation bins = 200 floats,
  * no normalisation, bilinear sampling; feature_detection.py:107-110) at nkp keypoints.  tiles: (nt, P, P) uint8 or
  * float32 (device).  weights_host[c] / radii[c]: centre-first half of the c-th incremental Gaussian kernel (host

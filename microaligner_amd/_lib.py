@@ -85,6 +85,8 @@ SIGNATURES = {
     "ma_fast_nms": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "ma_feature_extract": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.POINTER(_d)), C.POINTER(_i), C.POINTER(_d),
                                 C.POINTER(_d), _sz, _i, _vp, _vp, _vp, C.POINTER(_i)]),
+    "ma_feature_extract_enqueue": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.POINTER(_d)), C.POINTER(_i), C.POINTER(_d),
+                                        C.POINTER(_d), _sz, _i, _vp, _vp, _vp, C.POINTER(_i)]),
     "ma_daisy_describe": (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.POINTER(_d)), C.POINTER(_i), C.POINTER(_d), C.POINTER(_d),
                                _vp, _vp, _i, _vp]),
 }

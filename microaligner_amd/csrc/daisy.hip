@@ -767,6 +767,22 @@ int daisy_enqueue(ma_ctx* ctx, const void* tiles, int dtype, int nt, int P, cons
 
 } // namespace
 
+namespace {
+// content of window t of the row-major tile grid: the image rows [ty T - ov, ty T - ov + P) cut to the image, in window
+// coordinates -- geometry only, computed where it is used (a copy from a host buffer tied every call to the ctx's one
+// page-locked scratch, and so to a synchronisation before the next call could refill it)
+__global__ void dz_window_rects_kernel(DzRect* __restrict__ rects, int nb, int first, int ntx, int tile, int overlap, int P, int H,
+                                       int W)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nb) return;
+    const int t = first + k, ty = t / ntx, tx = t - ty * ntx, wy = ty * tile - overlap, wx = tx * tile - overlap;
+    DzRect r{max(0, -wy), min(P, H - wy), max(0, -wx), min(P, W - wx)};
+    if (r.y1 <= r.y0 || r.x1 <= r.x0) r = DzRect{0, 0, 0, 0};
+    rects[k] = r;
+}
+}  // namespace
+
 extern "C" {
 
 int ma_cut_tiles_u8(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int first_tile, int n_tiles,
@@ -847,9 +863,10 @@ int ma_daisy_describe(ma_ctx* ctx, const void* tiles, int dtype, int nt, int P, 
                          desc_out);
 }
 
-int ma_feature_extract(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int threshold, int limit,
-                       const double* const* weights_host, const int* radii, const double* cos_sin_host, const double* offs_host,
-                       size_t workspace_bytes, int capacity, float* desc_out, double* pts_out, int* resp_out, int* n_out_host)
+static int feature_extract_impl(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int threshold, int limit,
+                                const double* const* weights_host, const int* radii, const double* cos_sin_host,
+                                const double* offs_host, size_t workspace_bytes, int capacity, float* desc_out, double* pts_out,
+                                int* resp_out, int* n_out_host, bool wait)
 {
     MA_REQUIRE(ctx && img && weights_host && radii && cos_sin_host && offs_host && desc_out && pts_out && resp_out && n_out_host,
                "NULL argument");
@@ -892,21 +909,17 @@ int ma_feature_extract(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, 
     int* total = info + 2 * n_batches;
     char* big = ws + fixed;
     MA_HIP(hipMemsetAsync(total, 0, sizeof(int), ctx->stream));
-    DzRect* h_rects_all = (DzRect*)((char*)ctx->pinned + 64);
     for (int bi = 0; bi < n_batches; bi++) {
         const int first = bi * step, nb = (int)std::min<long long>(step, n_tiles - first);
-        // content of window t: image rows [ty T - ov, ty T - ov + P) cut to the image, in window coordinates
-        DzRect* h_rects = h_rects_all + (size_t)bi * step;
+        // the largest content rectangle of the batch (the launches are sized from it); the rectangles themselves: on the device
         DzSpan span{0, 0};
         for (int k = 0; k < nb; k++) {
             const int t = first + k, ty = t / ntx, tx = t - ty * ntx, wy = ty * tile - overlap, wx = tx * tile - overlap;
-            DzRect r{std::max(0, -wy), std::min(P, H - wy), std::max(0, -wx), std::min(P, W - wx)};
-            if (r.y1 <= r.y0 || r.x1 <= r.x0) r = DzRect{0, 0, 0, 0};
-            h_rects[k] = r;
-            span.h = std::max(span.h, r.y1 - r.y0);
-            span.w = std::max(span.w, r.x1 - r.x0);
+            const int y0 = std::max(0, -wy), y1 = std::min(P, H - wy), x0 = std::max(0, -wx), x1 = std::min(P, W - wx);
+            if (y1 > y0 && x1 > x0) { span.h = std::max(span.h, y1 - y0); span.w = std::max(span.w, x1 - x0); }
         }
-        MA_HIP(hipMemcpyAsync(rects, h_rects, (size_t)nb * sizeof(DzRect), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(dz_window_rects_kernel, dim3((nb + 255) / 256), dim3(256), 0, ctx->stream, rects, nb, first, ntx, tile,
+                           overlap, P, H, W);
         {
             MaProfScope ps(ctx, MA_K_OTHER, (double)nb * P * P);
             hipLaunchKernelGGL(cut_tiles_kernel, dim3((P + 255) / 256, P, nb), dim3(256), 0, ctx->stream, img, H, W, tile, overlap, ntx,
@@ -925,10 +938,31 @@ int ma_feature_extract(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, 
         MA_TRY(daisy_enqueue(ctx, tiles, MA_U8, nb, P, tb, radii, (float*)big, rects, span, kp_tile, kp_xy, nb * limit,
                              info + 2 * bi, desc_out));
     }
+    if (!wait) {      // n_out_host is page-locked: the count lands there in stream order
+        MA_HIP(hipMemcpyAsync(n_out_host, total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        return MA_OK;
+    }
     MA_HIP(hipMemcpyAsync(ctx->pinned, total, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MA_HIP(hipStreamSynchronize(ctx->stream));
     *n_out_host = *(const int*)ctx->pinned;
     return MA_OK;
+}
+
+int ma_feature_extract(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int threshold, int limit,
+                       const double* const* weights_host, const int* radii, const double* cos_sin_host, const double* offs_host,
+                       size_t workspace_bytes, int capacity, float* desc_out, double* pts_out, int* resp_out, int* n_out_host)
+{
+    return feature_extract_impl(ctx, img, H, W, tile, overlap, threshold, limit, weights_host, radii, cos_sin_host, offs_host,
+                                workspace_bytes, capacity, desc_out, pts_out, resp_out, n_out_host, true);
+}
+
+int ma_feature_extract_enqueue(ma_ctx* ctx, const uint8_t* img, int H, int W, int tile, int overlap, int threshold, int limit,
+                               const double* const* weights_host, const int* radii, const double* cos_sin_host,
+                               const double* offs_host, size_t workspace_bytes, int capacity, float* desc_out, double* pts_out,
+                               int* resp_out, int* n_out_pinned)
+{
+    return feature_extract_impl(ctx, img, H, W, tile, overlap, threshold, limit, weights_host, radii, cos_sin_host, offs_host,
+                                workspace_bytes, capacity, desc_out, pts_out, resp_out, n_out_pinned, false);
 }
 
 } // extern "C"

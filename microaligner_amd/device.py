@@ -487,7 +487,22 @@ class Context:
                 self._zero_flags = None
                 self.lib.ma_host_free(C.c_void_p(self._zero_flags_ptr))
                 self._zero_flags_ptr = None
+            if getattr(self, "_count_ptr", None):
+                self._count_words = None
+                self.lib.ma_host_free(C.c_void_p(self._count_ptr))
+                self._count_ptr = None
+            side, self._side = getattr(self, "_side", None), None
+            if side is not None:
+                side.close()
             self.lib.ma_ctx_destroy(self.handle)
+
+    def side_context(self):
+        """A second context on the same device, owned by this one (closed with it): an independent HIP stream, workspace and
+        pools for work that may run beside this context's -- FeatureRegistrator puts the reference image's features of every
+        level there while this one works through the moving image's coarse levels."""
+        if getattr(self, "_side", None) is None:
+            self._side = Context(self.device)
+        return self._side
 
     def __del__(self):
         try:
@@ -896,10 +911,29 @@ class Context:
                   n, desc.ptr)
         return desc if on_device else desc.numpy()
 
-    def feature_extract(self, img, tile, overlap, limit, weights, cos_sin, offsets, threshold=1, workspace_bytes=0):
+    _COUNT_SLOTS = 256
+
+    def _count_slot(self):
+        """A page-locked int32 for a count that arrives in stream order (ma_feature_extract_enqueue): a view of one word of a
+        small ring (a slot is read once, right after the event behind its call; 256 calls later it is handed out again)."""
+        if getattr(self, "_count_ptr", None) is None:
+            p = C.c_void_p()
+            L.check(self.lib.ma_host_alloc(4 * self._COUNT_SLOTS, C.byref(p)))
+            self._count_ptr = p.value
+            self._count_words = np.frombuffer((C.c_int * self._COUNT_SLOTS).from_address(p.value), np.int32)
+            self._count_next = 0
+        k = self._count_next
+        self._count_next = (k + 1) % self._COUNT_SLOTS
+        self._count_words[k] = 0
+        return self._count_words[k:k + 1], C.cast(C.c_void_p(self._count_ptr + 4 * k), C.POINTER(C.c_int))
+
+    def feature_extract(self, img, tile, overlap, limit, weights, cos_sin, offsets, threshold=1, workspace_bytes=0, wait=True):
         """tile_registration.find_features of a uint8 device image in one call (ma_feature_extract): returns
         (descriptors (n, 200) float32 DeviceArray, points (n, 2) float64 raw device buffer, responses (n,) int32 raw device
-        buffer, n); everything stays on the device, the keypoint count is the only thing that comes back."""
+        buffer, n); everything stays on the device, the keypoint count is the only thing that comes back.
+        wait=False (ma_feature_extract_enqueue): nothing is waited for; n is a one-element int32 array on page-locked memory
+        that holds the count once the stream has passed the call (the caller waits for an event recorded behind it), and
+        the descriptor array keeps its capacity as its first dimension until then."""
         if img.dtype != np.uint8 or img.ndim != 2:
             raise ValueError("FAST works on uint8 images (the DOG output)")
         H, W = img.shape
@@ -912,6 +946,12 @@ class Context:
         radii = (C.c_int * 3)(*[len(h) - 1 for h in halves])
         cs = np.ascontiguousarray(cos_sin, np.float64)
         of = np.ascontiguousarray(offsets, np.float64)
+        if not wait:
+            word, wp = self._count_slot()
+            self._run(self.lib.ma_feature_extract_enqueue, img.ptr, H, W, int(tile), int(overlap), int(threshold), int(limit), wptr,
+                      radii, cs.ctypes.data_as(C.POINTER(C.c_double)), of.ctypes.data_as(C.POINTER(C.c_double)),
+                      int(workspace_bytes), cap, desc.ptr, pts.ptr, resp.ptr, wp)
+            return desc, pts, resp, word
         n = C.c_int(0)
         self._run(self.lib.ma_feature_extract, img.ptr, H, W, int(tile), int(overlap), int(threshold), int(limit), wptr, radii,
                   cs.ctypes.data_as(C.POINTER(C.c_double)), of.ctypes.data_as(C.POINTER(C.c_double)), int(workspace_bytes), cap,

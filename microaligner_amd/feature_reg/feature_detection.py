@@ -39,6 +39,29 @@ class Features:
         f._descriptors, f._dev, f._pts_dev = desc, (ctx, pts, resp, n), pts
         return f
 
+    @classmethod
+    def pending_on_device(cls, ctx, desc, pts, resp, word):
+        """Features whose extraction has been ENQUEUED (Context.feature_extract(wait=False)): `word` receives the keypoint count
+        in stream order.  settle() -- after the caller has waited for an event recorded behind the extraction -- turns the
+        object into what on_device() (or, without keypoints, Features()) would have made."""
+        f = cls.on_device(ctx, desc, pts, resp, None)
+        f._pending = word
+        return f
+
+    def settle(self):
+        word = getattr(self, "_pending", None)
+        if word is None:
+            return self
+        self._pending = None
+        n = int(word[0])
+        ctx, pts, resp, _ = self._dev
+        if n == 0:
+            self._descriptors, self._dev, self._pts_dev = None, None, None
+        else:
+            self._descriptors.shape = (n, 200)
+            self._dev = (ctx, pts, resp, n)
+        return self
+
     @property
     def pts(self) -> Optional[np.ndarray]:
         if self._pts is None and self._dev is not None:
@@ -252,7 +275,7 @@ def find_features_device(tile_list: Sequence[np.ndarray], ctx, workspace_bytes: 
     return feats
 
 
-def find_features_of_device_image(img, tile_size: int, ctx, workspace_bytes: Optional[int] = None):
+def find_features_of_device_image(img, tile_size: int, ctx, workspace_bytes: Optional[int] = None, wait: bool = True):
     """tile_registration.find_features for a uint8 image that is already on the device (the DOG output), in one call
     (ma_feature_extract): the feature windows are cut there, the corners detected, ranked and cut to the per-tile limit
     there, the selection compacted in combine_features' layout (tile by tile, strongest first within a tile, tiles with
@@ -270,7 +293,9 @@ def find_features_of_device_image(img, tile_size: int, ctx, workspace_bytes: Opt
     halves, cos_sin, offsets = _daisy_tables(daisy)
     budget = DEVICE_WORKSPACE_BYTES if workspace_bytes is None else int(workspace_bytes)
     desc, pts, resp, n = ctx.feature_extract(img, tile_size, TILE_OVERLAP, limit, halves, cos_sin, offsets, threshold=1,
-                                             workspace_bytes=budget)
+                                             workspace_bytes=budget, wait=wait)
+    if not wait:          # enqueued: the count arrives in stream order (Features.settle)
+        return Features.pending_on_device(ctx, desc, pts, resp, n)
     if n == 0:
         return Features()
     return Features.on_device(ctx, desc, pts, resp, n)

@@ -14,7 +14,7 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-from ..device import DeviceArray, get_context
+from ..device import DeviceArray, get_context, use_context
 from ..shared_modules.img_checks import check_img_dims_match, check_img_is_2d_grey, check_img_is_provided
 from ..shared_modules.similarity_scoring import check_if_higher_similarity
 from . import affine_math
@@ -28,6 +28,12 @@ class _Level:
     factor: int
     image: DeviceArray
     features: Optional[Features] = None
+    gate: Optional[DeviceArray] = None      # dog(image): the reference half of the level's gate, kept for its rounds
+    # the level's reference-side work ENQUEUED on the side context (register()'s fast attempt): the context, an event behind the
+    # work, the side context's deferred max() == 0 report slots of the level's dog() calls
+    side: object = None
+    ready: object = None
+    zero_slots: tuple = ()
 
 
 class _ZeroMaxImage(Exception):
@@ -47,6 +53,7 @@ class FeatureRegistrator:
         self.compat_mov_getter = True   # the mov_img getter returns the REFERENCE image, as the reference's does; False: the moving image
         self._levels: List[_Level] = []   # reference side, coarsest first; kept for register(reuse_ref_img=True)
         self.fuse_rounds = True           # a round's device work in one C call (ma_feature_round) where that makes the same calls
+        self.overlap_reference = True     # the reference features of all levels on a second stream under the moving image's coarse levels
         self.features_on_host = False     # True: features and matching by the HOST statement (sparse_cpu.py, the definition the
         #                                     kernels reproduce; slow) -- dense steps stay on the device.  For cross-checks
         self._careful = False             # True: register() runs in the careful mode only (see register())
@@ -100,6 +107,62 @@ class FeatureRegistrator:
         for lvl in self._levels:
             lvl.features = self._features_of(lvl.image)
 
+    def _ref_side_enqueue(self, ctx):
+        """calc_ref_img_features() without waiting for anything: pyramid, dog() and feature extraction of every level of the
+        reference image ENQUEUED on the side context (a second HIP stream), coarsest level first, an event behind each level.
+        A level's rounds wait for ITS event only (_settle_level): the reference features of the finer levels -- three quarters
+        of the reference side's work sit in the finest one -- are computed while this context works through the moving image's
+        coarse levels, whose small kernels and synchronisations leave most of the chip idle.  Same kernels on the same inputs:
+        the features do not depend on the stream they were computed on."""
+        side = ctx.side_context()
+        if isinstance(self._ref_img, DeviceArray):
+            ctx.sync()                      # the caller's array may still be written on this context's stream
+        with use_context(side):
+            levels = [_Level(factor, img) for factor, img in self._build_pyramid(self._ref_img)]
+            for lvl in levels:
+                k0 = len(getattr(side, "_zero_pending", None) or ())
+                lvl.gate = self.dog(lvl.image, True)
+                pre = lvl.gate if self.use_dog else lvl.image
+                lvl.features = find_features_of_device_image(pre, self.tile_size, side, wait=False)
+                lvl.zero_slots = tuple((getattr(side, "_zero_pending", None) or ())[k0:])
+                lvl.side, lvl.ready = side, side.event()
+                side.record(lvl.ready)
+        self._levels = levels
+
+    def _settle_level(self, lvl: _Level):
+        """Wait for a level's reference-side work (if it was enqueued), take its keypoint count and its dog() reports."""
+        if lvl.ready is None:
+            return
+        side, ev, slots = lvl.side, lvl.ready, lvl.zero_slots
+        lvl.side, lvl.ready, lvl.zero_slots = None, None, ()
+        side.event_sync(ev)
+        side.event_destroy(ev)
+        lvl.features.settle()
+        if slots:
+            hit = bool(side._zero_flags[list(slots)].any())
+            pending = side._zero_pending
+            for k in slots:
+                if k in pending:
+                    pending.remove(k)
+            if hit:
+                raise _ZeroMaxImage()
+
+    def _drop_levels(self):
+        for lvl in self._levels:
+            if lvl.ready is not None:
+                try:
+                    lvl.side.event_destroy(lvl.ready)
+                except Exception:   # noqa: BLE001
+                    pass
+                lvl.ready = None
+        self._levels = []
+
+    def _can_overlap_reference(self, reuse_ref_img: bool) -> bool:
+        ref = self._ref_img
+        return (self._fast and self.overlap_reference and self.fuse_rounds and not self.features_on_host
+                and not (reuse_ref_img and self._levels) and np.ndim(ref) == 2
+                and (self.use_dog or np.dtype(getattr(ref, "dtype", None) or np.asarray(ref).dtype) == np.uint8))
+
     def register(self, reuse_ref_img: bool = False) -> np.ndarray:
         """:78-119: coarse-to-fine.  Every level sees the moving level pre-transformed by what the coarser levels
         found (their matrices brought to this level's pixel size), refines it in `num_iterations` gated rounds and
@@ -115,12 +178,14 @@ class FeatureRegistrator:
         if self._careful:
             return self._register(reuse_ref_img)
         get_context().any_deferred_zero()       # flags an aborted attempt (of any registrator on this context) left behind
+        if getattr(get_context(), "_side", None) is not None:
+            get_context()._side.any_deferred_zero()
         self._log_buf, self._log_shown, self._fast = [], 0, True
         try:
             result = self._register(reuse_ref_img)
         except _ZeroMaxImage:
             self._log_buf, self._fast = None, False
-            self._levels = []
+            self._drop_levels()
             self._careful = True
             try:
                 return self._register(False)      # prints from the first line the fast attempt had not shown
@@ -135,7 +200,9 @@ class FeatureRegistrator:
         return result
 
     def _register(self, reuse_ref_img: bool) -> np.ndarray:
-        if not (reuse_ref_img and self._levels):
+        if self._can_overlap_reference(reuse_ref_img):
+            self._ref_side_enqueue(get_context())
+        elif not (reuse_ref_img and self._levels):
             self.calc_ref_img_features()
             self._check_deferred()
         moving = self._build_pyramid(self._mov_img)
@@ -215,7 +282,8 @@ class FeatureRegistrator:
         if self.num_iterations < 1:
             raise ValueError("Number of iterations cannot be less than 1")
         ctx = get_context()
-        ref_gate = self.dog(ref_level.image, True)
+        self._settle_level(ref_level)
+        ref_gate = ref_level.gate if ref_level.gate is not None else self.dog(ref_level.image, True)
         rounds: List[np.ndarray] = []
         current = mov_level
         current_gate = None
