@@ -127,6 +127,7 @@ class FeatureRegistrator:
                 lvl.zero_slots = tuple((getattr(side, "_zero_pending", None) or ())[k0:])
                 lvl.side, lvl.ready = side, side.event()
                 side.record(lvl.ready)
+        self._drop_levels()                 # (events of an attempt that ended before its levels were settled)
         self._levels = levels
 
     def _settle_level(self, lvl: _Level):
