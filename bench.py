@@ -422,7 +422,7 @@ def lanes_leg(lanes, steps, device, dref, dmov, params, tile, overlap):
     return (max(b for _, b in spans) - min(a for a, _ in spans)) / (lanes * steps)
 
 
-def tile_lanes_leg(lanes, steps, device, work, params, use_features):
+def tile_lanes_leg(lanes, steps, device, work, params, use_features, replay_rounds=True):
     """Seconds per mosaic tile (cfg5) with `lanes` tiles in flight on one GPU: each lane -- own context (HIP stream, workspace,
     pools), own host thread -- takes every lanes-th tile of `work` and runs the whole composition on it (affine initialisation,
     transform, optical-flow refinement, warp), `steps` passes over its share.  A 4096^2 tile leaves most of the chip idle at
@@ -444,6 +444,7 @@ def tile_lanes_leg(lanes, steps, device, work, params, use_features):
                 if use_features:
                     freg = FeatureRegistrator()
                     freg.verbose = False
+                    freg.skip_repeated_rounds = replay_rounds
                 reg = OptFlowRegistrator()
                 reg.verbose = False
                 for k, v in params.items():
@@ -969,6 +970,8 @@ def main():
                          "rank with the whole-node rates (`host_modes`); auto: when N > 1 -- the modes that can fail to "
                          "scale -- at N = 1 the `variants` legs cover them")
     ap.add_argument("--host-mode-pairs", type=int, default=8, help="pairs per rank of the stream_pairs host modes")
+    ap.add_argument("--recompute-rounds", action="store_true",
+                    help="cfg5 --feature-init: FeatureRegistrator recomputes a round that follows a rejected one (default: replayed)")
     ap.add_argument("--host-mode-pages", type=int, default=8, help="uint16 pages per rank of the warp_pages host modes")
     ap.add_argument("--host-mode-timeout", type=float, default=300.0,
                     help="seconds a rank waits for the others at a barrier of the host modes before it leaves them (the headline "
@@ -1111,6 +1114,7 @@ def main():
         from microaligner_amd import FeatureRegistrator
         freg = FeatureRegistrator()
         freg.verbose = False
+        freg.skip_repeated_rounds = not args.recompute_rounds
     # (ref, mov) device pairs of this rank; for the mosaic workload also the known inverse matrix and the host arrays
     # FeatureRegistrator takes
     work = []
@@ -1310,6 +1314,9 @@ def main():
                        "devices": ndev, "affine_init": (("FeatureRegistrator on the numpy pair (upload timed)" if args.feature_init_from_host else
                                                          "FeatureRegistrator on the device-resident pair") if freg is not None else
                                                         "known matrix" if wl.get("affine") else None),
+                       "feature_rounds": (("a round after a rejected one is REPLAYED (same images, deterministic steps: same outcome), "
+                                           "not recomputed" if freg.skip_repeated_rounds else "every round recomputed")
+                                          if freg is not None else None),
                        "parallelism": f"{pairs_per_step} independent pairs per step dealt round-robin to {world} rank(s), "
                                       f"one rank per GPU, {min(world, ndev)} GPU(s), no collective on the data path"},
             # one compact row per kernel group; the full entries of the dominant kernel (`roofline`), the north-star kernel
@@ -1413,9 +1420,28 @@ def main():
                 informational(V, "page_warp", lambda: page_warp_leg(args.page_warps, H, W, reg.tile_size, reg.overlap))
             if args.lanes > 1 and inv_affine is None:
                 informational(V, f"lanes{args.lanes}", leg_lanes)
+        if world == 1 and freg is not None and not args.no_variants and freg.skip_repeated_rounds:
+            def leg_rounds_recomputed():
+                # the same tiles with every round of FeatureRegistrator recomputed, as the reference does (a round after a
+                # rejected one sees the same images and finds the same answer; the default replays it)
+                freg.skip_repeated_rounds = False
+                try:
+                    step()
+                    ctx.sync()
+                    tr0 = time.perf_counter()
+                    for _ in range(args.steps):
+                        step()
+                    ctx.sync()
+                    tr = (time.perf_counter() - tr0) / (args.steps * max(1, len(work)))
+                finally:
+                    freg.skip_repeated_rounds = True
+                return {"ms_per_tile": round(tr * 1e3, 3), "what": "FeatureRegistrator.skip_repeated_rounds = False: repeated rounds "
+                        "recomputed instead of replayed; same matrices (tests/test_feature_reg.py::test_replayed_rounds_equal_recomputed_rounds)"}
+            informational(res.setdefault("variants", {}), "feature_rounds_recomputed", leg_rounds_recomputed)
         if world == 1 and wl.get("affine") and not args.no_variants and args.lanes > 1 and len(work) > 1:
             def leg_tile_lanes():
-                tl, n = tile_lanes_leg(args.lanes, args.steps, ctx.device, work, params, freg is not None)
+                tl, n = tile_lanes_leg(args.lanes, args.steps, ctx.device, work, params, freg is not None,
+                                        freg.skip_repeated_rounds if freg is not None else True)
                 return {"ms_per_tile": round(tl * 1e3, 3), "value": round(H * W / tl / 1e6, 2), "unit": "Mpix/s", "tiles_in_flight": n,
                         "what": "the same tiles, the same statements, `tiles_in_flight` of them at a time on one GPU (one context "
                                 "and host thread each): what parallel.align_pairs(lanes=...) does; the headline runs them one "

@@ -54,6 +54,8 @@ class FeatureRegistrator:
         self._levels: List[_Level] = []   # reference side, coarsest first; kept for register(reuse_ref_img=True)
         self.fuse_rounds = True           # a round's device work in one C call (ma_feature_round) where that makes the same calls
         self.overlap_reference = True     # the reference features of all levels on a second stream under the moving image's coarse levels
+        self.skip_repeated_rounds = True  # a round after a REJECTED one sees the same images: its outcome is replayed, not recomputed
+        self._round_lines = None          # log lines of the round in progress (replayed by a repeated round)
         self.features_on_host = False     # True: features and matching by the HOST statement (sparse_cpu.py, the definition the
         #                                     kernels reproduce; slow) -- dense steps stay on the device.  For cross-checks
         self._careful = False             # True: register() runs in the careful mode only (see register())
@@ -87,6 +89,8 @@ class FeatureRegistrator:
         # dog() before it met an all-zero image (_check_deferred prints what it confirms: progress shows as it happens); the
         # careful re-run after a restart reproduces the confirmed lines and skips them.  Per object: no process-wide
         # redirection of stdout, which threads registering side by side would trip over.
+        if self._round_lines is not None:
+            self._round_lines.append(args)
         if self.verbose:
             if self._log_buf is not None:
                 self._log_buf.append(" ".join(str(a) for a in args))
@@ -283,13 +287,27 @@ class FeatureRegistrator:
         if self.num_iterations < 1:
             raise ValueError("Number of iterations cannot be less than 1")
         ctx = get_context()
+        self._round_lines = None
         self._settle_level(ref_level)
         ref_gate = ref_level.gate if ref_level.gate is not None else self.dog(ref_level.image, True)
         rounds: List[np.ndarray] = []
         current = mov_level
         current_gate = None
+        rejected_lines = None        # the log lines of the last round if it was rejected (nothing has changed since)
         for it in range(self.num_iterations):
             self._log("    Iteration", it + 1, "/", self.num_iterations)
+            if rejected_lines is not None and self.skip_repeated_rounds and not self.features_on_host:
+                # The round before was rejected: `current`, its dog() and the reference features are the very objects it saw,
+                # and every step of a round is a deterministic function of them (exact 2-NN search, RANSAC seeded per call,
+                # integer histograms, fixed-order sums) -- it would find the same matches, the same estimate and the same
+                # two scores, and be rejected again.  Its lines are replayed, its work is not repeated.  (The reference
+                # recomputes; with OpenCV's randomised FLANN trees and free-running RANSAC generator its repeat may differ --
+                # this package's definition of both steps is deterministic, oracle and device alike.)
+                for args in rejected_lines:
+                    self._log(*args)
+                rounds.append(affine_math.IDENTITY.copy())
+                continue
+            self._round_lines = []
             fused = self._fused_round(ctx, ref_level, ref_gate, current, current_gate)
             if fused is not None:
                 estimate, is_identity, candidate, candidate_gate, current_gate, improved = fused
@@ -314,6 +332,7 @@ class FeatureRegistrator:
             self._check_deferred()       # the gate has just synchronised: the flags of this round's dog() calls are in
             if any(improved) and plausible:
                 self._log("    Better alignment than before")
+                rejected_lines, self._round_lines = None, None
                 rounds.append(estimate)
                 if len(rounds) == 1 and current is mov_level:
                     current, current_gate = candidate, candidate_gate
@@ -321,6 +340,7 @@ class FeatureRegistrator:
                     current, current_gate = self.transform_img(mov_level, affine_math.compose(rounds)), None
             else:
                 self._log("    Worse alignment than before")
+                rejected_lines, self._round_lines = self._round_lines, None
                 rounds.append(affine_math.IDENTITY.copy())
         return affine_math.compose(rounds)
 

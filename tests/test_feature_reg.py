@@ -840,3 +840,37 @@ def test_fused_round_equals_the_step_by_step_entry_points(use_dog, dtype):
                 T = f.register()
             out.append((T, buf.getvalue()))
         assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.uint8, np.float32])
+def test_replayed_rounds_equal_recomputed_rounds(dtype):
+    """A round after a rejected one sees the same images and the same reference features, and every step of a round is
+    deterministic: FeatureRegistrator replays its outcome instead of recomputing it (`skip_repeated_rounds`).  The same matrix and
+    the same log, line for line, as with the replay off (every round recomputed), with the reference side on its own stream and
+    without, for pairs with accepted rounds, with rejected ones, and for an unrelated pair (every round rejected)."""
+    import contextlib
+    import io
+    from microaligner_amd import FeatureRegistrator
+    H, W = 900, 1000
+    ref = synthetic.make_cells(H, W, seed=41, dtype=dtype)
+    th = np.deg2rad(0.4)
+    pairs = [O.warp_affine(ref, np.array([[np.cos(th), -np.sin(th), 11.0], [np.sin(th), np.cos(th), -7.0]])),
+             O.warp_affine(ref, np.array([[1.0, 0.0, 3.0], [0.0, 1.0, -2.0]])),
+             synthetic.make_cells(H, W, seed=1041, dtype=dtype)]
+    replays = 0
+    for mov in pairs:
+        out = []
+        for skip, overlap in ((True, True), (False, True), (False, False)):
+            f = FeatureRegistrator()
+            f.num_pyr_lvl, f.num_iterations, f.tile_size = 2, 4, 400
+            f.skip_repeated_rounds, f.overlap_reference = skip, overlap
+            f.ref_img, f.mov_img = ref, mov
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                T = f.register()
+            out.append((T, buf.getvalue()))
+        assert all(np.array_equal(out[0][0], o[0]) and out[0][1] == o[1] for o in out[1:])
+        lines = out[0][1].splitlines()
+        replays += sum(1 for a, b in zip(lines, lines[4:]) if a.startswith("    Good matches") and a == b)
+    assert replays >= 3        # the cases do contain repeated rounds
